@@ -1,0 +1,171 @@
+// Internal declarations shared by the HIP translation units of liballophant_amx (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace amx {
+
+typedef _Float16 f16;
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// Precision modes (mirrors AMX_PREC_* in include/allophant_amx.h).
+//   *_X3: every GEMM-shaped product runs as hi*hi + lo*hi + hi*lo on two 16-bit planes per operand
+//         (x = hi + lo, hi = rn16(x), lo = rn16(x - hi)), fp32 accumulate: ~2^-21 (f16) / 2^-16 (bf16) relative.
+enum Precision { PREC_BF16 = 0, PREC_F16 = 1, PREC_BF16X3 = 2, PREC_F16X3 = 3 };
+inline int prec_planes(int p) { return p >= 2 ? 2 : 1; }
+
+template <typename T> struct Vec8;
+template <> struct Vec8<f16> { typedef f16x8 type; };
+template <> struct Vec8<bf16> { typedef bf16x8 type; };
+
+__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// hi/lo split of an fp32 value onto 16-bit planes
+template <typename T, int NT>
+__device__ __forceinline__ void split16(float x, T& hi, T& lo) {
+    hi = (T)x;
+    if (NT > 1) lo = (T)(x - (float)hi);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// GEMM:  C[M,N] = epilogue( A[M,K] . W[N,K]^T )      A and W are K-contiguous 16-bit planes
+// ---------------------------------------------------------------------------------------------------------------
+struct GemmParams {
+    // A operand: row r lives at A + (r / rows_per_batch) * a_batch_stride + (r % rows_per_batch) * lda  (elements).
+    // Overlapping rows (lda < K) express the strided 1-D convolutions as implicit GEMMs over channels-last input.
+    const void* A;
+    int64_t a_plane;  // distance hi plane -> lo plane (elements)
+    int64_t lda;
+    int64_t rows_per_batch;
+    int64_t a_batch_stride;
+    const void* W;  // [N, ldw]
+    int64_t w_plane;
+    int64_t ldw;
+    int M, N, K;  // K % 8 == 0
+    // grid.z batching (grouped positional convolution): pointer advances per z (elements)
+    int64_t za, zw, zbias, zout, zoutp;
+    // epilogue: v = acc*scale + bias[n]; v = act(v); v += residual[m,n]; if row masked: v = 0
+    float scale;
+    const float* bias;
+    int act;  // 0 none, 1 exact GELU
+    const float* residual;
+    int64_t ldr;
+    const int* row_len;  // optional [batch]: row r = b*rows_T + t is zeroed when t >= row_len[b]
+    int rows_T;
+    float* out_f32;
+    int64_t ldo;
+    void* out_p;  // 16-bit planes
+    int64_t out_plane;
+    int64_t ldp;
+    // QKV scatter epilogue (mode 1): columns [0,D) -> Q[b,h,t,dh], [D,2D) -> K[b,h,t,dh], [2D,3D) -> Vt[b,h,dh,perm(t)]
+    int mode;
+    void* q;
+    void* k;
+    void* vt;
+    int64_t qk_plane, vt_plane;
+    int T, Tp, H, dh;
+};
+
+void launch_gemm(int prec, const GemmParams& p, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------------------------
+// attention
+// ---------------------------------------------------------------------------------------------------------------
+struct AttnParams {
+    const void* q;  // [N,H,Tp,dh] planes (already scaled by dh^-0.5)
+    const void* k;  // [N,H,Tp,dh]
+    const void* vt; // [N,H,dh,Tp], key index permuted inside aligned groups of 16 (see vt_perm)
+    int64_t qk_plane, vt_plane;
+    void* out;  // [N*T, D] planes, column h*dh + d
+    int64_t out_plane;
+    const int* frame_len;  // [N] valid keys per utterance
+    int N, H, T, Tp, dh;
+};
+void launch_attention(int prec, const AttnParams& p, hipStream_t stream);
+
+// position of key t inside the transposed V image: bits 2 and 3 of t swapped, so that the 8 keys a lane needs for one
+// 32x32x16 MFMA k-step (accumulator-as-operand order, cdna_hip_programming.md section 3) are 16 contiguous bytes.
+__host__ __device__ __forceinline__ int vt_perm(int t) {
+    return (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// row-wise / elementwise kernels (amx_rowops.hip)
+// ---------------------------------------------------------------------------------------------------------------
+void launch_audio_stats(const float* audio, const int64_t* lengths, int N, int64_t L, double* partial, float* mean_rstd,
+                        int do_normalize, hipStream_t s);
+// conv layer 0 (C_in = 1) + LayerNorm(C) + GELU, fused; writes planes [N*T1, C]
+void launch_conv0(int prec, const float* audio, const int64_t* lengths, const float* mean_rstd, int N, int64_t L, int T1,
+                  int C, int k, int stride, const float* w /*[C,k]*/, const float* b, const float* gamma,
+                  const float* beta, float eps, int do_normalize, void* out, int64_t out_plane, hipStream_t s);
+// rows of width D: [LN1 -> GELU] (if gamma1) then [LN2] (if gamma2); outputs planes and/or f32
+void launch_rownorm(int prec, const float* x, int64_t ldx, int64_t M, int D, const float* gamma1, const float* beta1,
+                    int gelu, const float* gamma2, const float* beta2, float eps1, float eps2, void* out_p,
+                    int64_t out_plane, int64_t ldp, float* out_f32, int64_t ldo, hipStream_t s);
+// grouped, zero-padded 16-bit image of the (masked) projected features for the positional convolution
+void launch_posconv_pack(int prec, const float* h, int N, int T, int D, int G, int pad_front, int Tpad, void* out,
+                         int64_t out_plane, hipStream_t s);
+
+struct ConcatPart {
+    int type;     // 0: fp32 hidden rows -> planes; 1: softmax over logits columns
+    int src_col;  // column offset in the logits buffer (type 1)
+    int width;    // number of source columns
+    int dst_col;
+    const float* src;  // type 0: [M, width] fp32 (ld = width)
+};
+void launch_concat(int prec, const ConcatPart* parts_dev, int n_parts, const float* logits, int64_t ld_logits, int64_t M,
+                   void* out, int64_t out_plane, int64_t ldp, int kpad, hipStream_t s);
+
+struct OutDesc {
+    int col;          // column offset in the logits buffer
+    int C;            // classes incl. blank
+    int64_t out_off;  // offset (floats) of the [T,N,C] block in the output buffer
+};
+void launch_logsoftmax_out(const OutDesc* descs_dev, int n_out, const float* logits, int64_t ld, int N, int T,
+                           int log_probs, float* out, hipStream_t s);
+void launch_greedy_ctc(const OutDesc* descs_dev, int n_out, const float* out, const int* frame_len, int N, int T,
+                       int64_t* tokens, int64_t* timesteps, int* counts, float* scores, hipStream_t s);
+
+// weight packing helpers (device side; run once at amx_create / amx_set_inventory)
+void launch_pack_matrix(int prec, const float* src, int rows, int cols, int64_t src_row_stride, int64_t src_col_stride,
+                        float scale, void* dst, int64_t dst_plane, int64_t ldd, int cols_pad, hipStream_t s);
+void launch_pack_conv_w(int prec, const float* src /*[Co,Ci,k]*/, int Co, int Ci, int k, void* dst, int64_t dst_plane,
+                        hipStream_t s);
+void launch_pack_posconv_w(int prec, const float* g /*[k]*/, const float* v /*[D,cg,k]*/, int D, int cg, int k,
+                           float* norm_scratch, void* dst /*[G][cg][k*cg]*/, int64_t dst_plane, hipStream_t s);
+void launch_compose(int prec, const float* emb, int E, const int64_t* idx /*[P+1, F] absolute rows, row 0 = blank*/,
+                    int P1, int F, float* composed_f32 /*[P1,E]*/, void* dst, int64_t dst_plane, int64_t ldd,
+                    hipStream_t s);
+void launch_scale_copy(const float* src, float* dst, int64_t n, float scale, hipStream_t s);
+
+}  // namespace amx

@@ -1,0 +1,288 @@
+"""TEST INFRASTRUCTURE ONLY: CPU oracle for the Allophant acoustic-encoder forward path (``Estimator.predict``).
+
+This is a from-scratch fp32 CPU restatement of the reference's algorithm for the hot path, written with plain
+``torch.nn.functional`` primitives (no ``transformers`` import, no reference import).  It is the checker for the HIP
+path in ``allophant_amd/csrc``; only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import it.  The product path never routes through it.
+
+PARITY PIN: this restatement is pinned against the *real* reference (imported in the build container through
+``oracle/ref_import.py``) by ``oracle/gen_golden.py``; the resulting inputs/outputs are committed under
+``tests/golden/`` and ``tests/test_oracle_golden.py`` re-checks the oracle against them on every run.  The upstream repo
+holds no tests or golden vectors for this path, so outputs of the reference itself are the pin.
+
+The heavy arithmetic of the path lives in a third-party dependency that is not vendored in /root/reference:
+``transformers==4.41.2`` (``pyproject.toml:23``), class ``Wav2Vec2Model`` with ``do_stable_layer_norm=True`` and
+``feat_extract_norm="layer"`` (XLS-R); the build container has transformers 5.15.0, which is what the goldens were
+generated with.  Its published algorithm is restated in ``wav2vec2_hidden_states`` below; the reference's own call
+site is ``allophant/network/acoustic_model.py:837-853``.
+
+Reference lines followed (all relative to /root/reference):
+  mask_sequence                     allophant/utils.py:45-76
+  zero_mean_unit_var_norm           allophant/network/acoustic_model.py:762-767
+  conv_length / downsampled_lengths allophant/network/frontend.py:192-203, acoustic_model.py:832-835
+  Wav2Vec2AcousticModel.forward     allophant/network/acoustic_model.py:837-853
+  HierarchicalProjection.forward    allophant/network/acoustic_model.py:471-524 (+ 309-330 dependency sizes)
+  HierarchicalClassifier.forward    allophant/network/acoustic_model.py:284-306
+  EmbeddingCompositionLayer         allophant/network/acoustic_model.py:191-234
+  AllophoneMapping.forward(predict) allophant/network/acoustic_model.py:161-167
+  AttributeGraph.sort               allophant/attribute_graph.py:124-199
+  Estimator.predict                 allophant/estimator.py:1035-1046
+  GreedyCTCDecoder.__call__         allophant/predictions.py:194-207
+"""
+from __future__ import annotations
+
+import math
+import re
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+OUTPUT = "OUTPUT"
+OUTPUT_PATTERN = re.compile(r"^OUTPUT(?:_(\d+))?$")  # allophant/config.py:636-637
+PHONEME = "phoneme"  # allophant/config.py:638
+PHONE = "phone"  # allophant/config.py:639
+BLANK_OFFSET = 1  # allophant/config.py:555
+
+_AM = "_acoustic_model._model."
+_PROJ = "_projection._layers."
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# integer / mask helpers
+# ----------------------------------------------------------------------------------------------------------------
+def mask_sequence(lengths: Tensor, max_length: Optional[int] = None) -> Tensor:
+    """allophant/utils.py:45-76 (batch_first, non-inverse form used by the hot path)."""
+    if max_length is None:
+        max_length = int(lengths.max())
+    return torch.arange(max_length).unsqueeze(0) < lengths.unsqueeze(1)
+
+
+def downsampled_lengths(lengths: Tensor, kernels: Sequence[int], strides: Sequence[int]) -> Tensor:
+    """frontend.py:192-203 with use_padding=False applied once per conv layer (acoustic_model.py:832-835)."""
+    for k, s in zip(kernels, strides):
+        lengths = torch.div(lengths - k, s, rounding_mode="floor") + 1
+    return lengths
+
+
+def zero_mean_unit_var_norm(features: Tensor, lengths: Tensor, mask: Tensor) -> Tensor:
+    """acoustic_model.py:762-767.  NB the mean sums the *padded* row (relies on zero padding)."""
+    means = (features.sum(1) / lengths).unsqueeze(1)
+    deviations = (features - means) * mask
+    variances = (deviations ** 2).sum(1) / lengths
+    return ((features - means) / (variances.unsqueeze(1) + 1e-7).sqrt()) * mask
+
+
+def topological_order(classes: Sequence[Dict[str, Any]]) -> List[int]:
+    """Order in which ``AttributeGraph.sort`` (attribute_graph.py:124-199) yields the nodes of an acyclic graph.
+
+    Tarjan's SCC on a DAG emits every node when its depth-first visit finishes; roots are tried in index order and the
+    edges of a node are its class (non-OUTPUT) dependencies in listed order (attribute_graph.py:67-74).
+    """
+    index = {c["name"]: i for i, c in enumerate(classes)}
+    edges = [[index[d] for d in c["dependencies"] if not OUTPUT_PATTERN.match(d)] for c in classes]
+    state = [0] * len(classes)  # 0 new, 1 open, 2 done
+    order: List[int] = []
+
+    def visit(node: int) -> None:
+        if state[node] == 2:
+            return
+        if state[node] == 1:
+            raise ValueError("Dependency cycle detected")
+        state[node] = 1
+        for target in edges[node]:
+            visit(target)
+        state[node] = 2
+        order.append(node)
+
+    for root in range(len(classes)):
+        visit(root)
+    return order
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# wav2vec 2.0 (stable-layer-norm / layer-norm feature extractor variant), restated
+# ----------------------------------------------------------------------------------------------------------------
+def _pos_conv_weight(state: Dict[str, Tensor]) -> Tensor:
+    base = _AM + "encoder.pos_conv_embed.conv."
+    if base + "parametrizations.weight.original0" in state:
+        g = state[base + "parametrizations.weight.original0"]
+        v = state[base + "parametrizations.weight.original1"]
+    else:  # older torch / transformers naming
+        g = state[base + "weight_g"]
+        v = state[base + "weight_v"]
+    # weight_norm(dim=2): the norm is taken over dims (0, 1) separately for every kernel tap
+    norm = v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()
+    return v * (g / norm)
+
+
+def feature_encoder(x: Tensor, state: Dict[str, Tensor], spec: Dict[str, Any]) -> Tensor:
+    """7 x [Conv1d -> LayerNorm over channels -> exact GELU]; returns [N, T, C] (channels last)."""
+    h = x.unsqueeze(1)
+    for i, (k, s) in enumerate(zip(spec["conv_kernel"], spec["conv_stride"])):
+        p = f"{_AM}feature_extractor.conv_layers.{i}."
+        h = F.conv1d(h, state[p + "conv.weight"], state[p + "conv.bias"], stride=s)
+        h = h.transpose(-2, -1)
+        h = F.layer_norm(h, (h.shape[-1],), state[p + "layer_norm.weight"], state[p + "layer_norm.bias"], 1e-5)
+        h = h.transpose(-2, -1)
+        h = F.gelu(h)
+    return h.transpose(1, 2)
+
+
+def wav2vec2_hidden_states(
+    audio: Tensor, lengths: Tensor, state: Dict[str, Tensor], spec: Dict[str, Any], keep_intermediates: bool = False
+) -> Tuple[List[Tensor], Tensor, Dict[str, Tensor]]:
+    """Returns (hidden_states list of [N,T,D] incl. final LN state, frame lengths, intermediates)."""
+    eps = spec["eps"]
+    inter: Dict[str, Tensor] = {}
+    mask = mask_sequence(lengths)
+    if mask.shape[1] != audio.shape[1]:
+        raise ValueError("the batch must be padded to exactly max(lengths) (utils.py:62-63 / acoustic_model.py:765-767)")
+    x = zero_mean_unit_var_norm(audio, lengths, mask) if spec.get("do_normalize", True) else audio
+    if keep_intermediates:
+        inter["normed_audio"] = x
+    feats = feature_encoder(x, state, spec)  # [N, T, C]
+    if keep_intermediates:
+        inter["conv_out"] = feats
+    frame_lengths = downsampled_lengths(lengths, spec["conv_kernel"], spec["conv_stride"])
+    T = feats.shape[1]
+    frame_mask = torch.arange(T).unsqueeze(0) < frame_lengths.unsqueeze(1)  # == _get_feature_vector_attention_mask
+
+    p = _AM + "feature_projection."
+    h = F.layer_norm(feats, (feats.shape[-1],), state[p + "layer_norm.weight"], state[p + "layer_norm.bias"], eps)
+    h = F.linear(h, state[p + "projection.weight"], state[p + "projection.bias"])
+    h = h * frame_mask.unsqueeze(-1)  # hidden_states[~mask] = 0
+
+    k = spec["pos_kernel"]
+    pos = F.conv1d(
+        h.transpose(1, 2), _pos_conv_weight(state), state[_AM + "encoder.pos_conv_embed.conv.bias"],
+        padding=k // 2, groups=spec["pos_groups"],
+    )
+    if k % 2 == 0:
+        pos = pos[:, :, :-1]
+    h = h + F.gelu(pos).transpose(1, 2)
+
+    H = spec["heads"]
+    D = h.shape[-1]
+    dh = D // H
+    N = h.shape[0]
+    # additive key-padding bias (finfo.min on padded keys; padded *queries* are still computed)
+    bias = torch.zeros(N, 1, 1, T)
+    bias.masked_fill_(~frame_mask[:, None, None, :], torch.finfo(torch.float32).min)
+    hidden_states: List[Tensor] = []
+    for i in range(spec["layers"]):
+        hidden_states.append(h)
+        p = f"{_AM}encoder.layers.{i}."
+        a = F.layer_norm(h, (D,), state[p + "layer_norm.weight"], state[p + "layer_norm.bias"], eps)
+        q = F.linear(a, state[p + "attention.q_proj.weight"], state[p + "attention.q_proj.bias"])
+        kk = F.linear(a, state[p + "attention.k_proj.weight"], state[p + "attention.k_proj.bias"])
+        v = F.linear(a, state[p + "attention.v_proj.weight"], state[p + "attention.v_proj.bias"])
+        q = q.view(N, T, H, dh).transpose(1, 2)
+        kk = kk.view(N, T, H, dh).transpose(1, 2)
+        v = v.view(N, T, H, dh).transpose(1, 2)
+        scores = torch.matmul(q, kk.transpose(2, 3)) * (dh ** -0.5) + bias
+        attn = torch.matmul(torch.softmax(scores, dim=-1), v)
+        attn = attn.transpose(1, 2).reshape(N, T, D)
+        h = h + F.linear(attn, state[p + "attention.out_proj.weight"], state[p + "attention.out_proj.bias"])
+        f = F.layer_norm(h, (D,), state[p + "final_layer_norm.weight"], state[p + "final_layer_norm.bias"], eps)
+        f = F.gelu(F.linear(f, state[p + "feed_forward.intermediate_dense.weight"],
+                            state[p + "feed_forward.intermediate_dense.bias"]))
+        h = h + F.linear(f, state[p + "feed_forward.output_dense.weight"], state[p + "feed_forward.output_dense.bias"])
+    h = F.layer_norm(h, (D,), state[_AM + "encoder.layer_norm.weight"], state[_AM + "encoder.layer_norm.bias"], eps)
+    hidden_states.append(h)
+    return hidden_states, frame_lengths, inter
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# hierarchical multi-head projection
+# ----------------------------------------------------------------------------------------------------------------
+def category_offsets_from_table(train_table: Tensor) -> Tensor:
+    """acoustic_model.py:196-207: offsets = cumsum([1, n_0, n_1, ...])[:-1] with n_f = max(column f) + 1."""
+    num_categories = torch.cat((torch.zeros(1, dtype=torch.long), train_table.long().max(0).values)) + 1
+    return num_categories.cumsum(0)[:-1]
+
+
+def composed_embeddings(embedding: Tensor, tfi: Tensor, offsets: Tensor) -> Tensor:
+    """acoustic_model.py:219-232: [E, P+1] matrix of the blank embedding (row 0) and per-phone sums."""
+    indices = tfi.long() + offsets.unsqueeze(0)
+    phones = F.embedding_bag(indices, embedding, mode="sum")
+    blank = F.embedding_bag(torch.zeros(1, 1, dtype=torch.long), embedding, mode="sum")
+    return torch.cat((blank, phones)).T
+
+
+def projection_forward(
+    hidden_states: List[Tensor], state: Dict[str, Tensor], spec: Dict[str, Any], tfi: Optional[Tensor],
+    category_offsets: Optional[Tensor] = None,
+) -> Dict[str, Tensor]:
+    """HierarchicalProjection.forward in predict mode on time-major inputs ([T,N,D] each); returns raw logits."""
+    outputs: Dict[str, Tensor] = {f"{OUTPUT}_{i}": h for i, h in enumerate(hidden_states)}
+    outputs[OUTPUT] = hidden_states[-1]
+    blanks = bool(spec.get("dependency_blanks", True))
+    classes = spec["classes"]
+    result: Dict[str, Tensor] = {}
+    for ci in topological_order(classes):
+        node = classes[ci]
+        name, deps = node["name"], node["dependencies"]
+        if len(deps) == 1 and OUTPUT_PATTERN.match(deps[0]):
+            u = outputs[deps[0]]
+        else:
+            parts = []
+            for d in deps:
+                if OUTPUT_PATTERN.match(d):
+                    parts.append(outputs[d])
+                else:
+                    logits = outputs[d] if blanks else outputs[d][..., BLANK_OFFSET:]
+                    parts.append(torch.softmax(logits, -1))
+            u = torch.cat(parts, -1)
+        p = f"{_PROJ}{name}."
+        y = F.linear(u, state[p + "_time_distributed_layer.weight"], state[p + "_time_distributed_layer.bias"])
+        emb_key = p + "_composition_layer._attribute_embeddings.weight"
+        if emb_key in state:
+            if tfi is None:
+                raise ValueError("the oracle takes the inventory explicitly (the training table is a non-persistent buffer)")
+            if category_offsets is None:
+                raise ValueError("category_offsets required for the composition layer")
+            composed = composed_embeddings(state[emb_key], tfi, category_offsets)
+            y = (y @ composed) / torch.tensor(math.sqrt(composed.shape[0]))
+        if name == PHONEME and spec.get("allophone_layer", False):
+            # AllophoneMapping.forward(predict=True): the same tensor under both names, "phone" first
+            result[PHONE] = y
+            outputs[PHONE] = y
+        result[name] = y
+        outputs[name] = y
+    return result
+
+
+def predict(
+    audio: Tensor, lengths: Tensor, state: Dict[str, Tensor], spec: Dict[str, Any], tfi: Optional[Tensor] = None,
+    category_offsets: Optional[Tensor] = None, log_probabilities: bool = True, keep_intermediates: bool = False,
+):
+    """Estimator.predict restated.  Returns (outputs: name -> [T,N,C], frame lengths[, intermediates])."""
+    with torch.inference_mode():
+        hidden, frame_lengths, inter = wav2vec2_hidden_states(audio, lengths, state, spec, keep_intermediates)
+        time_major = [h.transpose(0, 1) for h in hidden]
+        logits = projection_forward(time_major, state, spec, tfi, category_offsets)
+        if log_probabilities:
+            logits = {k: F.log_softmax(v, -1) for k, v in logits.items()}
+        if keep_intermediates:
+            inter["hidden_states"] = hidden
+            return logits, frame_lengths, inter
+        return logits, frame_lengths
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# greedy CTC
+# ----------------------------------------------------------------------------------------------------------------
+def greedy_ctc(log_emissions: Tensor, lengths: Tensor, blank: int = 0):
+    """predictions.py:194-207 on batch-major [N,T,C]; returns per utterance (tokens, 1-based timesteps, score)."""
+    values, indices = torch.max(log_emissions, dim=-1)
+    out = []
+    for i in range(indices.shape[0]):
+        length = int(lengths[i])
+        idx = indices[i, :length]
+        decoded, sizes = torch.unique_consecutive(idx, return_counts=True)
+        keep = decoded != blank
+        timesteps = (sizes.cumsum(0) - sizes + 1)[keep]
+        out.append((decoded[keep], timesteps, values[i, :length].sum()))
+    return out
