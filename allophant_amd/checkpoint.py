@@ -1,0 +1,111 @@
+"""Reader for checkpoint dicts in the reference ``Checkpoint`` schema (allophant/estimator.py:199-249).
+
+The reference stores ``Checkpoint.Schema().dump(checkpoint)`` with ``torch.save``: a plain dict with the fields
+``config, allophant_version, feature_size, sample_rate, attribute_graph{nodes, node_indices, edges}, epoch,
+phonetic_indexer_state, dataset_meta_data, model_state, additional, history, optimization_states``.  Only the fields that
+shape the prediction path are read here; the encoder shape is XLS-R-300m (``nn.acoustic_model.model_id``,
+default_config.toml:34-37) unless the checkpoint carries an explicit ``additional["amx_encoder"]`` override (synthetic
+checkpoints used by the plumbing tests -- real hub checkpoints are not reachable offline).
+"""
+from __future__ import annotations
+
+from typing import Any, Dict
+
+import torch
+
+from . import spec as _spec
+
+XLSR_MODEL_IDS = ("facebook/wav2vec2-xls-r-300m",)
+
+
+def make_checkpoint(spec: Dict[str, Any], state_dict: Dict[str, torch.Tensor], synthetic_encoder: bool = False) -> Dict[str, Any]:
+    """Synthetic checkpoint dict with the reference's field names (used by tests and the config-1 plumbing case)."""
+    classes = spec["classes"]
+    nodes = [
+        {"name": c["name"], "size": c["size"], "time_layer_config": None, "dependencies": list(c["dependencies"])}
+        for c in classes
+    ]
+    index = {c["name"]: i for i, c in enumerate(classes)}
+    edges = [[index[d] for d in c["dependencies"] if not _spec.OUTPUT_PATTERN.match(d)] for c in classes]
+    projection = {
+        "classes": [{"name": c["name"], "dependencies": list(c["dependencies"]), "time_layer": None, "loss": {"type": "CTC"}}
+                    for c in classes],
+        "feature_set": "phoible",
+        "phoneme_layer": "allophones" if spec.get("allophone_layer") else "shared",
+        "acoustic_model_dropout": 0.0,
+        "dependency_blanks": bool(spec.get("dependency_blanks", True)),
+        "allophone_l2_alpha": 10.0,
+        "embedding_composition": {"embedding_size": spec["embedding_size"]} if spec.get("embedding_size") else None,
+    }
+    additional: Dict[str, Any] = {}
+    if synthetic_encoder:
+        additional["amx_encoder"] = {k: spec[k] for k in (
+            "conv_dim", "conv_kernel", "conv_stride", "hidden", "layers", "heads", "ffn", "pos_kernel", "pos_groups", "eps",
+            "do_normalize")}
+    if spec.get("composition_categories") is not None:
+        additional["amx_composition_categories"] = list(spec["composition_categories"])
+    if spec.get("shared_phones") is not None:
+        additional["amx_shared_phones"] = int(spec["shared_phones"])
+    return {
+        "config": {"nn": {"projection": projection,
+                          "acoustic_model": {"type": "wav2vec2-pretrained", "model_id": XLSR_MODEL_IDS[0]},
+                          "loss": {"type": "CTC"}}},
+        "allophant_version": "1.0.0",
+        "feature_size": 1,
+        "sample_rate": 16000,
+        "attribute_graph": {"nodes": nodes, "node_indices": index, "edges": edges},
+        "epoch": {"epoch": 0, "step": 0},
+        "phonetic_indexer_state": None,
+        "dataset_meta_data": [],
+        "model_state": state_dict,
+        "additional": additional,
+        "history": [],
+        "optimization_states": None,
+    }
+
+
+def spec_from_checkpoint(checkpoint: Dict[str, Any]) -> Dict[str, Any]:
+    for field in ("config", "attribute_graph", "model_state", "sample_rate", "feature_size"):
+        if field not in checkpoint:
+            raise ValueError(f"checkpoint is missing the field {field!r} of the reference Checkpoint schema")
+    if checkpoint["sample_rate"] != 16000:
+        # acoustic_model.py:788-794
+        raise ValueError(
+            "Audio resampling config and the sampling rate required by Wav2Vec2 do not match. "
+            f"Expected 16000kHz, got {checkpoint['sample_rate']}kHz")
+    nn_config = checkpoint["config"]["nn"]
+    additional = checkpoint.get("additional") or {}
+    acoustic = nn_config.get("acoustic_model", {})
+    if "amx_encoder" in additional:
+        encoder = dict(additional["amx_encoder"])
+    elif acoustic.get("model_id") in XLSR_MODEL_IDS:
+        encoder = _spec.xlsr_300m_encoder()
+    else:
+        raise ValueError(f"Unsupported model type: {acoustic.get('type')!r} / {acoustic.get('model_id')!r}")
+    projection = nn_config["projection"]
+    spec = dict(encoder)
+    spec["classes"] = [
+        {"name": n["name"], "size": int(n["size"]), "dependencies": list(n["dependencies"])}
+        for n in checkpoint["attribute_graph"]["nodes"]
+    ]
+    if any(n.get("time_layer_config") for n in checkpoint["attribute_graph"]["nodes"]):
+        raise ValueError("classifiers with a `time_layer` are not supported by the MI355X path yet")
+    spec["dependency_blanks"] = bool(projection.get("dependency_blanks", True))
+    composition = projection.get("embedding_composition")
+    spec["embedding_size"] = int(composition["embedding_size"]) if composition else None
+    spec["allophone_layer"] = projection.get("phoneme_layer", "shared") != "shared"
+    state = checkpoint["model_state"]
+    emb_key = "_projection._layers.phoneme._composition_layer._attribute_embeddings.weight"
+    spec["composition_categories"] = additional.get("amx_composition_categories")
+    if spec["embedding_size"] and spec["composition_categories"] is None:
+        raise ValueError(
+            "composition checkpoints need the per-feature category counts (`_category_offsets` is a non-persistent "
+            f"buffer upstream); table rows available: {state[emb_key].shape[0] if emb_key in state else 'n/a'}")
+    if spec["allophone_layer"]:
+        key = "_projection._layers.phoneme._allophone_layer._allophone_matrices"
+        if "amx_shared_phones" in additional:
+            spec["shared_phones"] = int(additional["amx_shared_phones"])
+        elif key in state:
+            spec["shared_phones"] = int(state[key].shape[1]) - 1
+    _spec.validate(spec)
+    return spec

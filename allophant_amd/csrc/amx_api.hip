@@ -1,0 +1,971 @@
+// C ABI of liballophant_amx (see include/allophant_amx.h): model construction from a reference state_dict, inventory
+// composition, and the forward pass orchestration (kernel sequence on one HIP stream).
+#include "../../include/allophant_amx.h"
+#include "amx_common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace amx;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Layer {
+    float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    void *wqkv, *wo, *w1, *w2;
+    float *bqkv, *bo, *b1, *b2;
+};
+
+// One GEMM (or GEMM pair for the composition head) of the hierarchical projection
+struct HeadStep {
+    std::vector<int> classes;   // classes computed by this step (stacked rows of W), evaluation order
+    bool direct_output;         // A operand = final LayerNorm planes (single "OUTPUT" dependency)
+    std::vector<ConcatPart> parts;  // otherwise: concatenation recipe (src pointers filled per forward)
+    std::vector<int> part_dep;      // per part: class index (>=0) or output code (<0)
+    int K, Kpad;                // input width
+    void* W;                    // planes [rows, Kpad]
+    float* bias;                // [rows]
+    int rows;                   // sum of out_features
+    bool composed;              // rows == embedding_size, followed by the composition product
+    ConcatPart* parts_dev;
+};
+
+}  // namespace
+
+struct amx_handle_s {
+    int device = 0;
+    amx_config cfg{};
+    std::vector<amx_class_desc> classes;
+    std::vector<int> order;
+    int prec = AMX_PREC_F16X3, NT = 2;
+    std::string err;
+    std::vector<void*> allocs;
+    int64_t weight_bytes = 0, ws_bytes = 0;
+
+    // weights
+    float *c0_w = nullptr, *c0_b = nullptr;
+    float* conv_b[AMX_MAX_CONV] = {};
+    float* conv_g[AMX_MAX_CONV] = {};
+    float* conv_be[AMX_MAX_CONV] = {};
+    void* conv_w[AMX_MAX_CONV] = {};
+    float *fp_g = nullptr, *fp_b = nullptr, *fp_bias = nullptr;
+    void* fp_w = nullptr;
+    void* pos_w = nullptr;
+    float* pos_b = nullptr;
+    std::vector<Layer> layers;
+    float *fln_g = nullptr, *fln_b = nullptr;
+    std::vector<HeadStep> steps;
+    float* emb = nullptr;  // composition embedding table [rows, E]
+    int emb_rows = 0;
+    int composed_class = -1;
+    std::vector<bool> need_hidden;
+
+    // inventory
+    int P1 = 0;  // phones + blank, 0 = not set
+    void* composed_w = nullptr;
+    float* composed_f32 = nullptr;
+    int64_t* inv_idx = nullptr;
+    int inv_cap = 0;
+
+    // logits layout
+    std::vector<int> col, width;  // per class
+    int ld_logits = 0;
+    std::vector<amx_output_desc> outputs;  // relative to N, T of the last layout computation
+    std::vector<OutDesc> out_unique, out_all;
+    OutDesc *out_unique_dev = nullptr, *out_all_dev = nullptr;
+    int layout_N = -1;
+    int64_t layout_T = -1;
+
+    // workspace
+    struct WS {
+        void* p = nullptr;
+        size_t bytes = 0;
+    };
+    std::map<std::string, WS> ws;
+    int64_t* h_lengths_pinned = nullptr;
+    int* h_frames_pinned = nullptr;
+    int pinned_cap = 0;
+    // last forward geometry
+    int last_N = 0;
+    int64_t last_L = 0, last_T = 0;
+    bool last_keep = false;
+};
+
+namespace {
+
+#define HIPCHK(h, expr)                                                                             \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) {                                                                     \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                           \
+            return AMX_EHIP;                                                                        \
+        }                                                                                           \
+    } while (0)
+
+int fail(amx_handle h, int code, const std::string& msg) {
+    if (h) h->err = msg;
+    g_create_error = msg;
+    return code;
+}
+
+void* dev_alloc(amx_handle h, size_t bytes, bool weight = true) {
+    void* p = nullptr;
+    if (bytes == 0) bytes = 16;
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    h->allocs.push_back(p);
+    if (weight) h->weight_bytes += (int64_t)bytes;
+    return p;
+}
+
+int ws_get(amx_handle h, const char* name, size_t bytes, void** out, bool zero_on_grow = false) {
+    auto& w = h->ws[name];
+    if (w.bytes < bytes) {
+        if (w.p) {
+            HIPCHK(h, hipDeviceSynchronize());
+            HIPCHK(h, hipFree(w.p));
+            h->ws_bytes -= (int64_t)w.bytes;
+            w.p = nullptr;
+            w.bytes = 0;
+        }
+        size_t want = bytes + 256;
+        if (hipMalloc(&w.p, want) != hipSuccess) return fail(h, AMX_ENOMEM, std::string("workspace allocation failed: ") + name);
+        w.bytes = want;
+        h->ws_bytes += (int64_t)want;
+        if (zero_on_grow) HIPCHK(h, hipMemset(w.p, 0, want));
+    }
+    *out = w.p;
+    return AMX_OK;
+}
+
+int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+struct TensorMap {
+    std::map<std::string, const amx_tensor*> m;
+    const amx_tensor* get(const std::string& k) const {
+        auto it = m.find(k);
+        return it == m.end() ? nullptr : it->second;
+    }
+};
+
+const std::string AM = "_acoustic_model._model.";
+const std::string PROJ = "_projection._layers.";
+
+// evaluation order of the classifier graph = order in which AttributeGraph.sort() yields nodes
+// (reference attribute_graph.py:124-199): depth-first post-order, roots in index order, edges in listed order.
+int evaluation_order(const std::vector<amx_class_desc>& cls, std::vector<int>& order, std::string& err) {
+    int n = (int)cls.size();
+    std::vector<int> state(n, 0);
+    order.clear();
+    for (int root = 0; root < n; ++root) {
+        if (state[root]) continue;
+        std::vector<std::pair<int, int>> stack;
+        stack.push_back({root, 0});
+        state[root] = 1;
+        while (!stack.empty()) {
+            auto [node, edge] = stack.back();
+            stack.pop_back();
+            std::vector<int> deps;
+            for (int i = 0; i < cls[node].n_deps; ++i)
+                if (cls[node].deps[i] >= 0) deps.push_back(cls[node].deps[i]);
+            if (edge < (int)deps.size()) {
+                stack.push_back({node, edge + 1});
+                int t = deps[edge];
+                if (t >= n) { err = "dependency index out of range"; return AMX_EINVAL; }
+                if (state[t] == 1) { err = std::string("Dependency cycle detected at ") + cls[t].name; return AMX_EINVAL; }
+                if (state[t] == 0) { state[t] = 1; stack.push_back({t, 0}); }
+            } else {
+                state[node] = 2;
+                order.push_back(node);
+            }
+        }
+    }
+    return AMX_OK;
+}
+
+}  // namespace
+
+// =================================================================================================================
+// creation
+// =================================================================================================================
+static int upload_f32(amx_handle h, const TensorMap& tm, const std::string& key, int64_t numel, float** out, float scale = 1.f,
+                      float* staging = nullptr) {
+    const amx_tensor* t = tm.get(key);
+    if (!t) return fail(h, AMX_EINVAL, "missing tensor in state_dict: " + key);
+    if (t->numel != numel)
+        return fail(h, AMX_EINVAL, "tensor " + key + " has " + std::to_string(t->numel) + " elements, expected " + std::to_string(numel));
+    float* d = (float*)dev_alloc(h, (size_t)numel * 4);
+    if (!d) return fail(h, AMX_ENOMEM, "device allocation failed for " + key);
+    if (scale == 1.f) {
+        HIPCHK(h, hipMemcpy(d, t->data, (size_t)numel * 4, hipMemcpyHostToDevice));
+    } else {
+        HIPCHK(h, hipMemcpy(staging, t->data, (size_t)numel * 4, hipMemcpyHostToDevice));
+        launch_scale_copy(staging, d, numel, scale, 0);
+        HIPCHK(h, hipDeviceSynchronize());
+    }
+    *out = d;
+    return AMX_OK;
+}
+
+// uploads a [rows, cols] fp32 matrix and packs it as planes at row offset `row0` of dst [*, ldd]
+static int pack_linear(amx_handle h, const TensorMap& tm, const std::string& key, int rows, int cols, float scale, void* dst,
+                       int64_t plane, int64_t ldd, int row0, int cols_pad, float* staging) {
+    const amx_tensor* t = tm.get(key);
+    if (!t) return fail(h, AMX_EINVAL, "missing tensor in state_dict: " + key);
+    if (t->numel != (int64_t)rows * cols)
+        return fail(h, AMX_EINVAL, "tensor " + key + " has " + std::to_string(t->numel) + " elements, expected " +
+                                       std::to_string((int64_t)rows * cols));
+    HIPCHK(h, hipMemcpy(staging, t->data, (size_t)t->numel * 4, hipMemcpyHostToDevice));
+    launch_pack_matrix(h->prec, staging, rows, cols, cols, 1, scale, (char*)dst + (size_t)row0 * ldd * 2, plane, ldd, cols_pad, 0);
+    HIPCHK(h, hipDeviceSynchronize());
+    return AMX_OK;
+}
+
+static void* alloc_planes(amx_handle h, int64_t elems_per_plane) {
+    return dev_alloc(h, (size_t)elems_per_plane * 2 * h->NT);
+}
+
+extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, const amx_class_desc* classes, int n_classes,
+                          const amx_tensor* tensors, int n_tensors) {
+    if (!out || !cfg || !classes || !tensors) return fail(nullptr, AMX_EINVAL, "null argument");
+    *out = nullptr;
+    if (cfg->abi_version != AMX_ABI_VERSION) return fail(nullptr, AMX_EINVAL, "ABI version mismatch");
+    if (cfg->n_conv < 2 || cfg->n_conv > AMX_MAX_CONV) return fail(nullptr, AMX_EINVAL, "n_conv out of range");
+    if (cfg->hidden % cfg->heads != 0 || cfg->hidden / cfg->heads != 64)
+        return fail(nullptr, AMX_EINVAL, "head_dim must be 64 (hidden / heads)");
+    if (cfg->hidden > 1024 || cfg->hidden % 8 || cfg->conv_dim > 1024 || cfg->conv_dim % 8)
+        return fail(nullptr, AMX_EINVAL, "hidden and conv_dim must be multiples of 8 and <= 1024");
+    if (cfg->conv_dim >= 64 && cfg->conv_dim % 64) return fail(nullptr, AMX_EINVAL, "conv_dim must be < 64 or a multiple of 64");
+    if (cfg->conv_kernel[0] > 16) return fail(nullptr, AMX_EINVAL, "first conv kernel must be <= 16");
+    if (cfg->hidden % cfg->pos_groups != 0 || (cfg->hidden / cfg->pos_groups) % 8 || cfg->hidden / cfg->pos_groups > 64)
+        return fail(nullptr, AMX_EINVAL, "hidden / pos_groups must be a multiple of 8 and <= 64");
+    if (cfg->ffn % 8) return fail(nullptr, AMX_EINVAL, "ffn must be a multiple of 8");
+    if (cfg->precision < 0 || cfg->precision > 3) return fail(nullptr, AMX_EINVAL, "unknown precision");
+    if (cfg->embedding_size % 8) return fail(nullptr, AMX_EINVAL, "embedding_size must be a multiple of 8");
+    if (n_classes < 1) return fail(nullptr, AMX_EINVAL, "Each model needs at least one classifier");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(nullptr, AMX_EHIP, "no HIP device available: liballophant_amx has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(nullptr, AMX_EINVAL, "device index out of range");
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, AMX_EHIP, "hipSetDevice failed");
+
+    amx_handle h = new amx_handle_s();
+    h->device = device;
+    h->cfg = *cfg;
+    h->prec = cfg->precision;
+    h->NT = prec_planes(cfg->precision);
+    h->classes.assign(classes, classes + n_classes);
+    auto bail = [&](int code) {
+        g_create_error = h->err;
+        amx_destroy(h);
+        return code;
+    };
+
+    // ---- validate the classifier graph (mirrors the ValueErrors of acoustic_model.py:353-466) ----
+    bool uses_output = false;
+    for (int i = 0; i < n_classes; ++i) {
+        const auto& c = h->classes[i];
+        for (int j = 0; j < i; ++j)
+            if (!strncmp(c.name, h->classes[j].name, AMX_NAME_LEN)) { h->err = "Dependencies contain duplicate keys"; return bail(AMX_EINVAL); }
+        if (!strncmp(c.name, "OUTPUT", 6)) { h->err = "'OUTPUT' is a reserved keyword"; return bail(AMX_EINVAL); }
+        if (c.n_deps < 1 || c.n_deps > AMX_MAX_DEPS) { h->err = "Each class projection requires a dependency"; return bail(AMX_EINVAL); }
+        for (int d = 0; d < c.n_deps; ++d) {
+            if (c.deps[d] < 0) {
+                uses_output = true;
+                if (c.deps[d] < -1 && -2 - c.deps[d] > cfg->layers) { h->err = "OUTPUT_i exceeds the number of encoder layers"; return bail(AMX_EINVAL); }
+            } else if (c.deps[d] >= n_classes) { h->err = "unknown dependency"; return bail(AMX_EINVAL); }
+        }
+    }
+    if (!uses_output) { h->err = "At least one of the input layers requires 'OUTPUT' as a dependency"; return bail(AMX_EINVAL); }
+    {
+        int rc = evaluation_order(h->classes, h->order, h->err);
+        if (rc) return bail(rc);
+    }
+
+    TensorMap tm;
+    int64_t max_numel = 0;
+    for (int i = 0; i < n_tensors; ++i) {
+        tm.m[tensors[i].name] = &tensors[i];
+        max_numel = std::max(max_numel, tensors[i].numel);
+    }
+    float* staging = nullptr;
+    if (hipMalloc(&staging, (size_t)max_numel * 4 + 16) != hipSuccess) { h->err = "staging allocation failed"; return bail(AMX_ENOMEM); }
+    struct StagingGuard {
+        float* p;
+        ~StagingGuard() { hipFree(p); }
+    } guard{staging};
+
+    const int C = cfg->conv_dim, D = cfg->hidden, F = cfg->ffn, NTp = h->NT;
+    const float eps = cfg->eps;
+    (void)eps;
+    int rc;
+#define TRY(x) do { rc = (x); if (rc) return bail(rc); } while (0)
+
+    // ---- feature extractor ----
+    {
+        std::string p = AM + "feature_extractor.conv_layers.0.";
+        TRY(upload_f32(h, tm, p + "conv.weight", (int64_t)C * cfg->conv_kernel[0], &h->c0_w));
+        int c_in = 1;
+        for (int i = 0; i < cfg->n_conv; ++i) {
+            p = AM + "feature_extractor.conv_layers." + std::to_string(i) + ".";
+            int k = cfg->conv_kernel[i];
+            TRY(upload_f32(h, tm, p + "conv.bias", C, &h->conv_b[i]));
+            TRY(upload_f32(h, tm, p + "layer_norm.weight", C, &h->conv_g[i]));
+            TRY(upload_f32(h, tm, p + "layer_norm.bias", C, &h->conv_be[i]));
+            if (i > 0) {
+                const amx_tensor* t = tm.get(p + "conv.weight");
+                if (!t || t->numel != (int64_t)C * c_in * k) { h->err = "missing or mis-shaped tensor " + p + "conv.weight"; return bail(AMX_EINVAL); }
+                int64_t plane = (int64_t)C * c_in * k;
+                h->conv_w[i] = alloc_planes(h, plane);
+                if (!h->conv_w[i]) { h->err = "device allocation failed"; return bail(AMX_ENOMEM); }
+                if (hipMemcpy(staging, t->data, (size_t)t->numel * 4, hipMemcpyHostToDevice) != hipSuccess) { h->err = "H2D failed"; return bail(AMX_EHIP); }
+                launch_pack_conv_w(h->prec, staging, C, c_in, k, h->conv_w[i], plane, 0);
+                if (hipDeviceSynchronize() != hipSuccess) { h->err = "pack_conv_w failed"; return bail(AMX_EHIP); }
+            }
+            c_in = C;
+        }
+    }
+    // ---- feature projection ----
+    {
+        std::string p = AM + "feature_projection.";
+        TRY(upload_f32(h, tm, p + "layer_norm.weight", C, &h->fp_g));
+        TRY(upload_f32(h, tm, p + "layer_norm.bias", C, &h->fp_b));
+        TRY(upload_f32(h, tm, p + "projection.bias", D, &h->fp_bias));
+        h->fp_w = alloc_planes(h, (int64_t)D * C);
+        if (!h->fp_w) { h->err = "device allocation failed"; return bail(AMX_ENOMEM); }
+        TRY(pack_linear(h, tm, p + "projection.weight", D, C, 1.f, h->fp_w, (int64_t)D * C, C, 0, C, staging));
+    }
+    // ---- positional conv (weight-norm folded) ----
+    {
+        std::string p = AM + "encoder.pos_conv_embed.conv.";
+        const int cg = D / cfg->pos_groups, k = cfg->pos_kernel;
+        const amx_tensor* g = tm.get(p + "parametrizations.weight.original0");
+        const amx_tensor* v = tm.get(p + "parametrizations.weight.original1");
+        if (!g) g = tm.get(p + "weight_g");
+        if (!v) v = tm.get(p + "weight_v");
+        if (!g || !v || g->numel != k || v->numel != (int64_t)D * cg * k) { h->err = "missing or mis-shaped positional conv weights"; return bail(AMX_EINVAL); }
+        TRY(upload_f32(h, tm, p + "bias", D, &h->pos_b));
+        float* gd = (float*)dev_alloc(h, (size_t)k * 4 * 2);
+        if (!gd) { h->err = "device allocation failed"; return bail(AMX_ENOMEM); }
+        if (hipMemcpy(gd, g->data, (size_t)k * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(staging, v->data, (size_t)v->numel * 4, hipMemcpyHostToDevice) != hipSuccess) { h->err = "H2D failed"; return bail(AMX_EHIP); }
+        int64_t plane = (int64_t)D * cg * k;
+        h->pos_w = alloc_planes(h, plane);
+        if (!h->pos_w) { h->err = "device allocation failed"; return bail(AMX_ENOMEM); }
+        launch_pack_posconv_w(h->prec, gd, staging, D, cg, k, gd + k, h->pos_w, plane, 0);
+        if (hipDeviceSynchronize() != hipSuccess) { h->err = "pack_posconv_w failed"; return bail(AMX_EHIP); }
+    }
+    // ---- encoder layers ----
+    h->layers.resize(cfg->layers);
+    const float qscale = 1.0f / sqrtf(64.0f);
+    for (int l = 0; l < cfg->layers; ++l) {
+        Layer& ly = h->layers[l];
+        std::string p = AM + "encoder.layers." + std::to_string(l) + ".";
+        TRY(upload_f32(h, tm, p + "layer_norm.weight", D, &ly.ln1_g));
+        TRY(upload_f32(h, tm, p + "layer_norm.bias", D, &ly.ln1_b));
+        TRY(upload_f32(h, tm, p + "final_layer_norm.weight", D, &ly.ln2_g));
+        TRY(upload_f32(h, tm, p + "final_layer_norm.bias", D, &ly.ln2_b));
+        ly.wqkv = alloc_planes(h, (int64_t)3 * D * D);
+        ly.wo = alloc_planes(h, (int64_t)D * D);
+        ly.w1 = alloc_planes(h, (int64_t)F * D);
+        ly.w2 = alloc_planes(h, (int64_t)D * F);
+        ly.bqkv = (float*)dev_alloc(h, (size_t)3 * D * 4);
+        if (!ly.wqkv || !ly.wo || !ly.w1 || !ly.w2 || !ly.bqkv) { h->err = "device allocation failed"; return bail(AMX_ENOMEM); }
+        const char* names[3] = {"q_proj", "k_proj", "v_proj"};
+        for (int j = 0; j < 3; ++j) {
+            float sc = j == 0 ? qscale : 1.f;
+            TRY(pack_linear(h, tm, p + "attention." + names[j] + ".weight", D, D, sc, ly.wqkv, (int64_t)3 * D * D, D, j * D, D, staging));
+            const amx_tensor* b = tm.get(p + "attention." + names[j] + ".bias");
+            if (!b || b->numel != D) { h->err = "missing tensor " + p + "attention." + names[j] + ".bias"; return bail(AMX_EINVAL); }
+            if (hipMemcpy(staging, b->data, (size_t)D * 4, hipMemcpyHostToDevice) != hipSuccess) { h->err = "H2D failed"; return bail(AMX_EHIP); }
+            launch_scale_copy(staging, ly.bqkv + j * D, D, sc, 0);
+            if (hipDeviceSynchronize() != hipSuccess) { h->err = "scale_copy failed"; return bail(AMX_EHIP); }
+        }
+        TRY(pack_linear(h, tm, p + "attention.out_proj.weight", D, D, 1.f, ly.wo, (int64_t)D * D, D, 0, D, staging));
+        TRY(upload_f32(h, tm, p + "attention.out_proj.bias", D, &ly.bo));
+        TRY(pack_linear(h, tm, p + "feed_forward.intermediate_dense.weight", F, D, 1.f, ly.w1, (int64_t)F * D, D, 0, D, staging));
+        TRY(upload_f32(h, tm, p + "feed_forward.intermediate_dense.bias", F, &ly.b1));
+        TRY(pack_linear(h, tm, p + "feed_forward.output_dense.weight", D, F, 1.f, ly.w2, (int64_t)D * F, F, 0, F, staging));
+        TRY(upload_f32(h, tm, p + "feed_forward.output_dense.bias", D, &ly.b2));
+    }
+    TRY(upload_f32(h, tm, AM + "encoder.layer_norm.weight", D, &h->fln_g));
+    TRY(upload_f32(h, tm, AM + "encoder.layer_norm.bias", D, &h->fln_b));
+
+    // ---- hierarchical projection plan ----
+    h->need_hidden.assign(cfg->layers + 1, false);
+    const bool blanks = cfg->dependency_blanks != 0;
+    auto dep_width = [&](int dep) -> int {
+        if (dep < 0) return D;
+        return h->classes[dep].size + (blanks ? 1 : 0);
+    };
+    for (size_t oi = 0; oi < h->order.size(); ++oi) {
+        int ci = h->order[oi];
+        const amx_class_desc& c = h->classes[ci];
+        bool composed = cfg->embedding_size > 0 && !strcmp(c.name, "phoneme");
+        if (composed) {
+            if (c.out_features != cfg->embedding_size) { h->err = "phoneme out_features must equal embedding_size"; return bail(AMX_EINVAL); }
+            h->composed_class = ci;
+        }
+        bool direct = c.n_deps == 1 && c.deps[0] == AMX_DEP_OUTPUT;
+        int K = 0;
+        for (int d = 0; d < c.n_deps; ++d) {
+            K += dep_width(c.deps[d]);
+            if (c.deps[d] < -1) h->need_hidden[-2 - c.deps[d]] = true;
+        }
+        // stack onto the previous step when both read the final LayerNorm output directly and neither is composed
+        if (direct && !composed && !h->steps.empty() && h->steps.back().direct_output && !h->steps.back().composed) {
+            h->steps.back().classes.push_back(ci);
+            h->steps.back().rows += c.out_features;
+            continue;
+        }
+        HeadStep st{};
+        st.classes = {ci};
+        st.direct_output = direct;
+        st.K = K;
+        st.Kpad = round_up(K, 8);
+        st.rows = c.out_features;
+        st.composed = composed;
+        st.parts_dev = nullptr;
+        if (!direct) {
+            int colp = 0;
+            for (int d = 0; d < c.n_deps; ++d) {
+                ConcatPart pt{};
+                int dep = c.deps[d];
+                pt.type = dep < 0 ? 0 : 1;
+                pt.width = dep_width(dep);
+                pt.dst_col = colp;
+                pt.src_col = 0;
+                pt.src = nullptr;
+                colp += pt.width;
+                st.parts.push_back(pt);
+                st.part_dep.push_back(dep);
+            }
+        }
+        h->steps.push_back(st);
+    }
+    for (auto& st : h->steps) {
+        st.W = alloc_planes(h, (int64_t)st.rows * st.Kpad);
+        st.bias = (float*)dev_alloc(h, (size_t)st.rows * 4);
+        if (!st.W || !st.bias) { h->err = "device allocation failed"; return bail(AMX_ENOMEM); }
+        int row0 = 0;
+        for (int ci : st.classes) {
+            const amx_class_desc& c = h->classes[ci];
+            std::string p = PROJ + c.name + "._time_distributed_layer.";
+            TRY(pack_linear(h, tm, p + "weight", c.out_features, st.K, 1.f, st.W, (int64_t)st.rows * st.Kpad, st.Kpad, row0, st.Kpad, staging));
+            const amx_tensor* b = tm.get(p + "bias");
+            if (!b || b->numel != c.out_features) { h->err = "missing tensor " + p + "bias"; return bail(AMX_EINVAL); }
+            if (hipMemcpy(st.bias + row0, b->data, (size_t)c.out_features * 4, hipMemcpyHostToDevice) != hipSuccess) { h->err = "H2D failed"; return bail(AMX_EHIP); }
+            row0 += c.out_features;
+        }
+        if (!st.parts.empty()) {
+            st.parts_dev = (ConcatPart*)dev_alloc(h, st.parts.size() * sizeof(ConcatPart));
+            if (!st.parts_dev) { h->err = "device allocation failed"; return bail(AMX_ENOMEM); }
+        }
+    }
+    if (h->composed_class >= 0) {
+        std::string key = PROJ + "phoneme._composition_layer._attribute_embeddings.weight";
+        const amx_tensor* t = tm.get(key);
+        if (!t || t->numel % cfg->embedding_size) { h->err = "missing tensor " + key; return bail(AMX_EINVAL); }
+        h->emb_rows = (int)(t->numel / cfg->embedding_size);
+        TRY(upload_f32(h, tm, key, t->numel, &h->emb));
+    }
+#undef TRY
+    if (hipDeviceSynchronize() != hipSuccess) { h->err = "device synchronisation failed after packing"; return bail(AMX_EHIP); }
+    *out = h;
+    return AMX_OK;
+}
+
+extern "C" int amx_destroy(amx_handle h) {
+    if (!h) return AMX_OK;
+    hipSetDevice(h->device);
+    hipDeviceSynchronize();
+    for (void* p : h->allocs) hipFree(p);
+    for (auto& kv : h->ws)
+        if (kv.second.p) hipFree(kv.second.p);
+    if (h->h_lengths_pinned) hipHostFree(h->h_lengths_pinned);
+    if (h->h_frames_pinned) hipHostFree(h->h_frames_pinned);
+    delete h;
+    return AMX_OK;
+}
+
+extern "C" const char* amx_last_error(amx_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int64_t amx_device_bytes(amx_handle h) { return h ? h->weight_bytes + h->ws_bytes : 0; }
+
+// =================================================================================================================
+// inventory
+// =================================================================================================================
+extern "C" int amx_set_inventory(amx_handle h, const int64_t* tfi, int phones, int features, const int64_t* offsets) {
+    if (!h) return AMX_EINVAL;
+    if (h->composed_class < 0) return fail(h, AMX_ESTATE, "model has no embedding composition layer");
+    if (!tfi || !offsets || phones < 1 || features < 1) return fail(h, AMX_EINVAL, "bad inventory arguments");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int P1 = phones + 1, E = h->cfg.embedding_size;
+    std::vector<int64_t> idx((size_t)P1 * features, -1);
+    idx[0] = 0;  // blank embedding = row 0 (acoustic_model.py:226-228)
+    for (int p = 0; p < phones; ++p)
+        for (int f = 0; f < features; ++f) {
+            int64_t r = tfi[(size_t)p * features + f] + offsets[f];
+            if (r < 0 || r >= h->emb_rows) return fail(h, AMX_EINVAL, "composition feature index out of range of the embedding table");
+            idx[(size_t)(p + 1) * features + f] = r;
+        }
+    void *idx_dev, *cw, *cf;
+    int rc;
+    if ((rc = ws_get(h, "inv_idx", idx.size() * 8, &idx_dev))) return rc;
+    if ((rc = ws_get(h, "composed_w", (size_t)P1 * E * 2 * h->NT, &cw))) return rc;
+    if ((rc = ws_get(h, "composed_f32", (size_t)P1 * E * 4, &cf))) return rc;
+    HIPCHK(h, hipMemcpy(idx_dev, idx.data(), idx.size() * 8, hipMemcpyHostToDevice));
+    launch_compose(h->prec, h->emb, E, (const int64_t*)idx_dev, P1, features, (float*)cf, cw, (int64_t)P1 * E, E, 0);
+    HIPCHK(h, hipDeviceSynchronize());
+    h->composed_w = cw;
+    h->composed_f32 = (float*)cf;
+    h->P1 = P1;
+    h->layout_N = -1;  // logits layout depends on the inventory size
+    return AMX_OK;
+}
+
+// =================================================================================================================
+// layout
+// =================================================================================================================
+static int64_t frames_of(const amx_config& c, int64_t len) {
+    for (int i = 0; i < c.n_conv; ++i) len = (len - c.conv_kernel[i]) / c.conv_stride[i] + 1;  // floor for len >= kernel
+    return len;
+}
+
+static int compute_layout(amx_handle h, int N, int64_t L) {
+    if (N < 1 || L < 1) return fail(h, AMX_EINVAL, "empty batch");
+    int64_t T = L;
+    for (int i = 0; i < h->cfg.n_conv; ++i) {
+        if (T < h->cfg.conv_kernel[i]) return fail(h, AMX_EINVAL, "utterances are shorter than the receptive field of the feature extractor");
+        T = (T - h->cfg.conv_kernel[i]) / h->cfg.conv_stride[i] + 1;
+    }
+    if (T > 1 << 20) return fail(h, AMX_EINVAL, "utterance too long");
+    if (h->composed_class >= 0 && h->P1 == 0)
+        return fail(h, AMX_ESTATE, "composition model needs amx_set_inventory before prediction (the training inventory is a non-persistent buffer upstream)");
+    if (h->layout_N == N && h->layout_T == T) return AMX_OK;
+    const int nc = (int)h->classes.size();
+    h->col.assign(nc, 0);
+    h->width.assign(nc, 0);
+    int colp = 0;
+    for (int ci : h->order) {
+        h->col[ci] = colp;
+        h->width[ci] = ci == h->composed_class ? h->P1 : h->classes[ci].out_features;
+        colp += h->width[ci];
+    }
+    h->ld_logits = round_up(colp, 4);
+    h->outputs.clear();
+    h->out_unique.clear();
+    h->out_all.clear();
+    int64_t off = 0;
+    for (int ci : h->order) {
+        const amx_class_desc& c = h->classes[ci];
+        OutDesc od{h->col[ci], h->width[ci], off};
+        h->out_unique.push_back(od);
+        bool is_phoneme = !strcmp(c.name, "phoneme");
+        if (is_phoneme && h->cfg.allophone_layer) {
+            amx_output_desc d{};
+            strncpy(d.name, "phone", AMX_NAME_LEN - 1);
+            d.classes = h->width[ci];
+            d.offset = off;
+            h->outputs.push_back(d);
+            h->out_all.push_back(od);
+        }
+        amx_output_desc d{};
+        strncpy(d.name, c.name, AMX_NAME_LEN - 1);
+        d.classes = h->width[ci];
+        d.offset = off;
+        h->outputs.push_back(d);
+        h->out_all.push_back(od);
+        off += (int64_t)T * N * h->width[ci];
+    }
+    void *a, *b;
+    int rc;
+    if ((rc = ws_get(h, "out_unique", h->out_unique.size() * sizeof(OutDesc), &a))) return rc;
+    if ((rc = ws_get(h, "out_all", h->out_all.size() * sizeof(OutDesc), &b))) return rc;
+    HIPCHK(h, hipMemcpy(a, h->out_unique.data(), h->out_unique.size() * sizeof(OutDesc), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(b, h->out_all.data(), h->out_all.size() * sizeof(OutDesc), hipMemcpyHostToDevice));
+    h->out_unique_dev = (OutDesc*)a;
+    h->out_all_dev = (OutDesc*)b;
+    h->layout_N = N;
+    h->layout_T = T;
+    return AMX_OK;
+}
+
+static int64_t layout_total(amx_handle h, int N, int64_t T) {
+    int64_t tot = 0;
+    for (auto& o : h->out_unique) tot += (int64_t)T * N * o.C;
+    return tot;
+}
+
+extern "C" int amx_output_layout(amx_handle h, int N, int64_t L, amx_output_desc* descs, int* n_outputs, int64_t* T,
+                                 int64_t* total) {
+    if (!h) return AMX_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = compute_layout(h, N, L);
+    if (rc) return rc;
+    if (n_outputs) *n_outputs = (int)h->outputs.size();
+    if (T) *T = h->layout_T;
+    if (total) *total = layout_total(h, N, h->layout_T);
+    if (descs) memcpy(descs, h->outputs.data(), h->outputs.size() * sizeof(amx_output_desc));
+    return AMX_OK;
+}
+
+// =================================================================================================================
+// forward
+// =================================================================================================================
+extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* lengths, int N, int64_t L, float* out,
+                           int64_t* out_lengths, uint32_t flags, void* stream_) {
+    if (!h) return AMX_EINVAL;
+    if (!audio || !lengths || !out) return fail(h, AMX_EINVAL, "null buffer");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream_;
+    int rc = compute_layout(h, N, L);
+    if (rc) return rc;
+    const amx_config& c = h->cfg;
+    const int NT = h->NT, prec = h->prec;
+    const int C = c.conv_dim, D = c.hidden, F = c.ffn, H = c.heads;
+    const bool keep = (flags & AMX_FLAG_KEEP_HIDDEN) != 0;
+
+    int64_t Ts[AMX_MAX_CONV + 1];
+    Ts[0] = L;
+    for (int i = 0; i < c.n_conv; ++i) Ts[i + 1] = (Ts[i] - c.conv_kernel[i]) / c.conv_stride[i] + 1;
+    const int T = (int)Ts[c.n_conv];
+    const int64_t M = (int64_t)N * T;
+    if (M * std::max(F, 3 * D) > (int64_t)INT32_MAX * 4 || (int64_t)N * Ts[1] > INT32_MAX)
+        return fail(h, AMX_EINVAL, "batch too large for 32-bit row indices");
+    const int Tp = round_up(T, 64);
+
+    int64_t maxlen = 0;
+    for (int n = 0; n < N; ++n) {
+        if (lengths[n] < 1 || lengths[n] > L) return fail(h, AMX_EINVAL, "lengths must lie in [1, L]");
+        maxlen = std::max(maxlen, lengths[n]);
+    }
+    if (maxlen != L)
+        return fail(h, AMX_EINVAL, "the batch must be padded to exactly max(lengths) (reference utils.py:62-63, acoustic_model.py:765-767)");
+
+    // ---- pinned host staging of lengths ----
+    if (h->pinned_cap < N) {
+        if (h->h_lengths_pinned) { hipStreamSynchronize(s); hipHostFree(h->h_lengths_pinned); hipHostFree(h->h_frames_pinned); }
+        HIPCHK(h, hipHostMalloc((void**)&h->h_lengths_pinned, (size_t)N * 8));
+        HIPCHK(h, hipHostMalloc((void**)&h->h_frames_pinned, (size_t)N * 4));
+        h->pinned_cap = N;
+    } else {
+        HIPCHK(h, hipStreamSynchronize(s));  // previous call may still be reading the pinned buffers
+    }
+    for (int n = 0; n < N; ++n) {
+        h->h_lengths_pinned[n] = lengths[n];
+        int64_t f = frames_of(c, lengths[n]);
+        if (lengths[n] < c.conv_kernel[0] || f < 1) return fail(h, AMX_EINVAL, "utterance shorter than the receptive field");
+        h->h_frames_pinned[n] = (int)f;
+        if (out_lengths) out_lengths[n] = f;
+    }
+
+    // ---- workspace ----
+    void *d_len, *d_frames, *d_partial, *d_stats, *actA, *actB, *preln, *hbuf, *xp, *hg, *qb, *kb, *vtb, *ao, *ff, *hfin, *logits;
+    const int cg = D / c.pos_groups;
+    const int Tpad = T + c.pos_kernel;
+    const int64_t rows1 = (int64_t)N * Ts[1], rows2 = (int64_t)N * Ts[2];
+#define WS(name, bytes, ptr) do { if ((rc = ws_get(h, name, (size_t)(bytes), &ptr))) return rc; } while (0)
+    WS("len", (size_t)N * 8, d_len);
+    WS("frames", (size_t)N * 4, d_frames);
+    WS("partial", (size_t)N * 64 * 3 * 8, d_partial);
+    WS("stats", (size_t)N * 2 * 4, d_stats);
+    WS("actA", (size_t)rows1 * C * 2 * NT, actA);
+    WS("actB", (size_t)rows2 * C * 2 * NT, actB);
+    WS("preln", (size_t)rows2 * C * 4, preln);
+    WS("h", (size_t)M * D * 4, hbuf);
+    WS("xp", (size_t)M * D * 2 * NT, xp);
+    WS("hg", (size_t)N * Tpad * D * 2 * NT, hg);
+    const size_t qkv_bytes = (size_t)N * H * Tp * 64 * 2 * NT;
+    if ((rc = ws_get(h, "q", qkv_bytes, &qb, true))) return rc;
+    if ((rc = ws_get(h, "k", qkv_bytes, &kb, true))) return rc;
+    if ((rc = ws_get(h, "vt", qkv_bytes, &vtb, true))) return rc;
+    WS("ao", (size_t)M * D * 2 * NT, ao);
+    WS("ff", (size_t)M * F * 2 * NT, ff);
+    WS("hfin", (size_t)M * D * 4, hfin);
+    WS("logits", (size_t)M * h->ld_logits * 4, logits);
+    // K/V/Q padding rows [T, Tp) must stay finite: re-zero when the geometry changes
+    if (h->last_N != N || h->last_T != T) {
+        HIPCHK(h, hipMemsetAsync(qb, 0, qkv_bytes, s));
+        HIPCHK(h, hipMemsetAsync(kb, 0, qkv_bytes, s));
+        HIPCHK(h, hipMemsetAsync(vtb, 0, qkv_bytes, s));
+    }
+    const float* d_audio = audio;
+    float* d_out = out;
+    const int64_t total = layout_total(h, N, T);
+    if (flags & AMX_FLAG_HOST_IO) {
+        void *a, *o;
+        WS("audio_host_io", (size_t)N * L * 4, a);
+        WS("out_host_io", (size_t)total * 4, o);
+        HIPCHK(h, hipMemcpyAsync(a, audio, (size_t)N * L * 4, hipMemcpyHostToDevice, s));
+        d_audio = (const float*)a;
+        d_out = (float*)o;
+    }
+    std::vector<float*> saved(c.layers + 1, nullptr);
+    for (int l = 0; l < c.layers; ++l)
+        if (keep || h->need_hidden[l]) {
+            void* p;
+            std::string nm = "hid" + std::to_string(l);
+            WS(nm.c_str(), (size_t)M * D * 4, p);
+            saved[l] = (float*)p;
+        }
+    saved[c.layers] = (float*)hfin;
+    float* conv_dbg = nullptr;
+    if (keep) {
+        void* p;
+        WS("conv_dbg", (size_t)M * C * 4, p);
+        conv_dbg = (float*)p;
+    }
+
+    HIPCHK(h, hipMemcpyAsync(d_len, h->h_lengths_pinned, (size_t)N * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(d_frames, h->h_frames_pinned, (size_t)N * 4, hipMemcpyHostToDevice, s));
+
+    // ---- input normalisation statistics + conv layer 0 (fused norm + conv + LN + GELU) ----
+    launch_audio_stats(d_audio, (const int64_t*)d_len, N, L, (double*)d_partial, (float*)d_stats, c.do_normalize, s);
+    launch_conv0(prec, d_audio, (const int64_t*)d_len, (const float*)d_stats, N, L, (int)Ts[1], C, c.conv_kernel[0],
+                 c.conv_stride[0], h->c0_w, h->conv_b[0], h->conv_g[0], h->conv_be[0], 1e-5f, c.do_normalize, actA,
+                 rows1 * C, s);
+    // ---- conv layers 1..n-1: implicit GEMM over overlapping channels-last windows, then LN + GELU rows ----
+    void* cur = actA;
+    int64_t cur_plane = rows1 * C;
+    void* other = actB;
+    for (int i = 1; i < c.n_conv; ++i) {
+        const int64_t rows_out = (int64_t)N * Ts[i + 1];
+        GemmParams g{};
+        g.A = cur; g.a_plane = cur_plane; g.lda = (int64_t)c.conv_stride[i] * C; g.rows_per_batch = Ts[i + 1];
+        g.a_batch_stride = Ts[i] * C;
+        g.W = h->conv_w[i]; g.w_plane = (int64_t)C * C * c.conv_kernel[i]; g.ldw = (int64_t)C * c.conv_kernel[i];
+        g.M = (int)rows_out; g.N = C; g.K = C * c.conv_kernel[i];
+        g.scale = 1.f; g.bias = h->conv_b[i];
+        g.out_f32 = (float*)preln; g.ldo = C;
+        launch_gemm(prec, g, s);
+        const bool last = i == c.n_conv - 1;
+        const int64_t out_plane = rows_out * C;
+        if (!last) {
+            launch_rownorm(prec, (const float*)preln, C, rows_out, C, h->conv_g[i], h->conv_be[i], 1, nullptr, nullptr, 1e-5f,
+                           0.f, other, out_plane, C, nullptr, 0, s);
+        } else if (!keep) {
+            // last conv layer: LN + GELU, then the feature-projection LayerNorm in the same pass
+            launch_rownorm(prec, (const float*)preln, C, rows_out, C, h->conv_g[i], h->conv_be[i], 1, h->fp_g, h->fp_b, 1e-5f,
+                           c.eps, other, out_plane, C, nullptr, 0, s);
+        } else {
+            launch_rownorm(prec, (const float*)preln, C, rows_out, C, h->conv_g[i], h->conv_be[i], 1, nullptr, nullptr, 1e-5f,
+                           0.f, nullptr, 0, 0, conv_dbg, C, s);
+            launch_rownorm(prec, conv_dbg, C, rows_out, C, h->fp_g, h->fp_b, 0, nullptr, nullptr, c.eps, 0.f, other, out_plane,
+                           C, nullptr, 0, s);
+        }
+        std::swap(cur, other);
+        cur_plane = out_plane;
+    }
+    // ---- feature projection (+ zero padded frames) ----
+    {
+        GemmParams g{};
+        g.A = cur; g.a_plane = cur_plane; g.lda = C; g.rows_per_batch = M; g.a_batch_stride = 0;
+        g.W = h->fp_w; g.w_plane = (int64_t)D * C; g.ldw = C;
+        g.M = (int)M; g.N = D; g.K = C;
+        g.scale = 1.f; g.bias = h->fp_bias;
+        g.row_len = (const int*)d_frames; g.rows_T = T;
+        g.out_f32 = (float*)hbuf; g.ldo = D;
+        launch_gemm(prec, g, s);
+    }
+    // ---- positional conv embedding: h += GELU(grouped conv(h)) ----
+    {
+        launch_posconv_pack(prec, (const float*)hbuf, N, T, D, c.pos_groups, c.pos_kernel / 2, Tpad, hg,
+                            (int64_t)N * Tpad * D, s);
+        GemmParams g{};
+        g.A = hg; g.a_plane = (int64_t)N * Tpad * D; g.lda = cg; g.rows_per_batch = T; g.a_batch_stride = (int64_t)Tpad * cg;
+        g.za = (int64_t)N * Tpad * cg;
+        g.W = h->pos_w; g.w_plane = (int64_t)D * cg * c.pos_kernel; g.ldw = (int64_t)cg * c.pos_kernel;
+        g.zw = (int64_t)cg * cg * c.pos_kernel;
+        g.M = (int)M; g.N = cg; g.K = cg * c.pos_kernel;
+        g.scale = 1.f; g.bias = h->pos_b; g.zbias = cg; g.act = 1;
+        g.residual = (const float*)hbuf; g.ldr = D; g.out_f32 = (float*)hbuf; g.ldo = D; g.zout = cg;
+        launch_gemm_grouped(prec, g, c.pos_groups, s);
+    }
+    // ---- transformer encoder (pre-LN) ----
+    const int64_t xp_plane = M * D;
+    for (int l = 0; l < c.layers; ++l) {
+        const Layer& ly = h->layers[l];
+        if (saved[l]) HIPCHK(h, hipMemcpyAsync(saved[l], hbuf, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s));
+        launch_rownorm(prec, (const float*)hbuf, D, M, D, ly.ln1_g, ly.ln1_b, 0, nullptr, nullptr, c.eps, 0.f, xp, xp_plane, D,
+                       nullptr, 0, s);
+        {
+            GemmParams g{};
+            g.A = xp; g.a_plane = xp_plane; g.lda = D; g.rows_per_batch = M;
+            g.W = ly.wqkv; g.w_plane = (int64_t)3 * D * D; g.ldw = D;
+            g.M = (int)M; g.N = 3 * D; g.K = D;
+            g.scale = 1.f; g.bias = ly.bqkv;
+            g.mode = 1; g.q = qb; g.k = kb; g.vt = vtb;
+            g.qk_plane = (int64_t)N * H * Tp * 64; g.vt_plane = (int64_t)N * H * Tp * 64;
+            g.T = T; g.Tp = Tp; g.H = H; g.dh = 64;
+            launch_gemm(prec, g, s);
+        }
+        {
+            AttnParams a{};
+            a.q = qb; a.k = kb; a.vt = vtb;
+            a.qk_plane = (int64_t)N * H * Tp * 64; a.vt_plane = (int64_t)N * H * Tp * 64;
+            a.out = ao; a.out_plane = xp_plane;
+            a.frame_len = (const int*)d_frames;
+            a.N = N; a.H = H; a.T = T; a.Tp = Tp; a.dh = 64;
+            launch_attention(prec, a, s);
+        }
+        {
+            GemmParams g{};
+            g.A = ao; g.a_plane = xp_plane; g.lda = D; g.rows_per_batch = M;
+            g.W = ly.wo; g.w_plane = (int64_t)D * D; g.ldw = D;
+            g.M = (int)M; g.N = D; g.K = D;
+            g.scale = 1.f; g.bias = ly.bo;
+            g.residual = (const float*)hbuf; g.ldr = D; g.out_f32 = (float*)hbuf; g.ldo = D;
+            launch_gemm(prec, g, s);
+        }
+        launch_rownorm(prec, (const float*)hbuf, D, M, D, ly.ln2_g, ly.ln2_b, 0, nullptr, nullptr, c.eps, 0.f, xp, xp_plane, D,
+                       nullptr, 0, s);
+        {
+            GemmParams g{};
+            g.A = xp; g.a_plane = xp_plane; g.lda = D; g.rows_per_batch = M;
+            g.W = ly.w1; g.w_plane = (int64_t)F * D; g.ldw = D;
+            g.M = (int)M; g.N = F; g.K = D;
+            g.scale = 1.f; g.bias = ly.b1; g.act = 1;
+            g.out_p = ff; g.out_plane = M * F; g.ldp = F;
+            launch_gemm(prec, g, s);
+        }
+        {
+            GemmParams g{};
+            g.A = ff; g.a_plane = M * F; g.lda = F; g.rows_per_batch = M;
+            g.W = ly.w2; g.w_plane = (int64_t)D * F; g.ldw = F;
+            g.M = (int)M; g.N = D; g.K = F;
+            g.scale = 1.f; g.bias = ly.b2;
+            g.residual = (const float*)hbuf; g.ldr = D; g.out_f32 = (float*)hbuf; g.ldo = D;
+            launch_gemm(prec, g, s);
+        }
+    }
+    launch_rownorm(prec, (const float*)hbuf, D, M, D, h->fln_g, h->fln_b, 0, nullptr, nullptr, c.eps, 0.f, xp, xp_plane, D,
+                   (float*)hfin, D, s);
+
+    // ---- hierarchical projection ----
+    const int E = c.embedding_size;
+    void *ebuf = nullptr, *cat = nullptr;
+    int kcat = 0;
+    for (auto& st : h->steps) kcat = std::max(kcat, st.direct_output ? 0 : st.Kpad);
+    if (E > 0) WS("e", (size_t)M * E * 2 * NT, ebuf);
+    if (kcat > 0) WS("cat", (size_t)M * kcat * 2 * NT, cat);
+    const bool blanks = c.dependency_blanks != 0;
+    for (auto& st : h->steps) {
+        const void* A = xp;
+        int64_t a_plane = xp_plane, lda = D;
+        if (!st.direct_output) {
+            for (size_t i = 0; i < st.parts.size(); ++i) {
+                int dep = st.part_dep[i];
+                if (dep < 0) {
+                    st.parts[i].src = dep == AMX_DEP_OUTPUT ? (const float*)hfin : saved[-2 - dep];
+                } else {
+                    st.parts[i].src_col = h->col[dep] + (blanks ? 0 : 1);
+                    // a composed dependency has an inventory-dependent width; the classifier was trained on the training
+                    // inventory, so the widths must agree
+                    int w = h->width[dep] - (blanks ? 0 : 1);
+                    if (w != st.parts[i].width)
+                        return fail(h, AMX_EINVAL, "inventory size does not match the input width of a dependent classifier");
+                }
+            }
+            HIPCHK(h, hipMemcpyAsync(st.parts_dev, st.parts.data(), st.parts.size() * sizeof(ConcatPart), hipMemcpyHostToDevice, s));
+            HIPCHK(h, hipStreamSynchronize(s));  // st.parts is pageable host memory
+            launch_concat(prec, st.parts_dev, (int)st.parts.size(), (const float*)logits, h->ld_logits, M, cat, M * st.Kpad,
+                          st.Kpad, st.Kpad, s);
+            A = cat; a_plane = M * st.Kpad; lda = st.Kpad;
+        }
+        GemmParams g{};
+        g.A = A; g.a_plane = a_plane; g.lda = lda; g.rows_per_batch = M;
+        g.W = st.W; g.w_plane = (int64_t)st.rows * st.Kpad; g.ldw = st.Kpad;
+        g.M = (int)M; g.N = st.rows; g.K = st.Kpad;
+        g.scale = 1.f; g.bias = st.bias;
+        if (st.composed) {
+            g.out_p = ebuf; g.out_plane = M * E; g.ldp = E;
+            launch_gemm(prec, g, s);
+            // logits = (e @ composed) / sqrt(E)   (acoustic_model.py:234)
+            GemmParams g2{};
+            g2.A = ebuf; g2.a_plane = M * E; g2.lda = E; g2.rows_per_batch = M;
+            g2.W = h->composed_w; g2.w_plane = (int64_t)h->P1 * E; g2.ldw = E;
+            g2.M = (int)M; g2.N = h->P1; g2.K = E;
+            g2.scale = 1.0f / sqrtf((float)E);
+            g2.out_f32 = (float*)logits + h->col[st.classes[0]]; g2.ldo = h->ld_logits;
+            launch_gemm(prec, g2, s);
+        } else {
+            g.out_f32 = (float*)logits + h->col[st.classes[0]]; g.ldo = h->ld_logits;
+            launch_gemm(prec, g, s);
+        }
+    }
+    launch_logsoftmax_out(h->out_unique_dev, (int)h->out_unique.size(), (const float*)logits, h->ld_logits, N, T,
+                          (flags & AMX_FLAG_RAW_LOGITS) ? 0 : 1, d_out, s);
+    HIPCHK(h, hipGetLastError());
+    if (flags & AMX_FLAG_HOST_IO) {
+        HIPCHK(h, hipMemcpyAsync(out, d_out, (size_t)total * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipStreamSynchronize(s));
+    }
+    h->last_N = N; h->last_L = L; h->last_T = T; h->last_keep = keep;
+#undef WS
+    return AMX_OK;
+}
+
+extern "C" int amx_synchronize(amx_handle h, void* stream) {
+    if (!h) return AMX_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+    HIPCHK(h, hipGetLastError());
+    return AMX_OK;
+}
+
+extern "C" int amx_greedy_ctc(amx_handle h, const float* out, int N, int64_t L, int64_t* tokens, int64_t* timesteps,
+                              int32_t* counts, float* scores, void* stream) {
+    if (!h || !out || !tokens || !timesteps || !counts || !scores) return AMX_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (h->last_N != N || h->last_L != L || h->layout_N != N) return fail(h, AMX_ESTATE, "amx_greedy_ctc must follow amx_forward with the same batch geometry");
+    const int T = (int)h->last_T;
+    if ((size_t)T * 4 + 2048 > 64 * 1024) return fail(h, AMX_EINVAL, "utterance too long for the on-device greedy decoder");
+    launch_greedy_ctc(h->out_all_dev, (int)h->out_all.size(), out, (const int*)h->ws["frames"].p, N, T, tokens, timesteps,
+                      counts, scores, (hipStream_t)stream);
+    HIPCHK(h, hipGetLastError());
+    return AMX_OK;
+}
+
+extern "C" int amx_debug_fetch(amx_handle h, int what, int index, float* host_out, int64_t capacity, int64_t* ld_out) {
+    if (!h || !host_out) return AMX_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    const int64_t M = (int64_t)h->last_N * h->last_T;
+    const void* src = nullptr;
+    int64_t n = 0;
+    if (what == 0) {
+        if (!h->last_keep) return fail(h, AMX_ESTATE, "conv output is only kept with AMX_FLAG_KEEP_HIDDEN");
+        src = h->ws["conv_dbg"].p; n = M * h->cfg.conv_dim;
+    } else if (what == 1) {
+        if (index < 0 || index > h->cfg.layers) return fail(h, AMX_EINVAL, "hidden state index out of range");
+        std::string nm = index == h->cfg.layers ? "hfin" : "hid" + std::to_string(index);
+        if (!h->ws.count(nm) || !h->ws[nm].p || (index < h->cfg.layers && !h->last_keep && !h->need_hidden[index]))
+            return fail(h, AMX_ESTATE, "hidden state was not kept (AMX_FLAG_KEEP_HIDDEN)");
+        src = h->ws[nm].p; n = M * h->cfg.hidden;
+    } else if (what == 2) {
+        src = h->ws["logits"].p; n = M * h->ld_logits;
+        if (ld_out) *ld_out = h->ld_logits;
+    } else if (what == 3) {
+        // raw workspace bytes (developer diagnostics): index 0 actA, 1 actB, 2 preln
+        const char* names[3] = {"actA", "actB", "preln"};
+        if (index < 0 || index > 2) return fail(h, AMX_EINVAL, "bad raw buffer index");
+        auto& w = h->ws[names[index]];
+        src = w.p;
+        n = std::min<int64_t>(capacity, (int64_t)(w.bytes / 4));
+        if (ld_out) *ld_out = (int64_t)w.bytes;
+    } else {
+        return fail(h, AMX_EINVAL, "unknown debug item");
+    }
+    if (!src) return fail(h, AMX_ESTATE, "nothing to fetch before the first amx_forward");
+    if (capacity < n) return fail(h, AMX_EINVAL, "debug buffer too small");
+    HIPCHK(h, hipMemcpy(host_out, src, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return AMX_OK;
+}

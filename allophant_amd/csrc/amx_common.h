@@ -23,6 +23,9 @@ inline int prec_planes(int p) { return p >= 2 ? 2 : 1; }
 template <typename T> struct Vec8;
 template <> struct Vec8<f16> { typedef f16x8 type; };
 template <> struct Vec8<bf16> { typedef bf16x8 type; };
+template <typename T> struct Vec4;
+template <> struct Vec4<f16> { typedef f16x4 type; };
+template <> struct Vec4<bf16> { typedef bf16x4 type; };
 
 __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
@@ -37,11 +40,18 @@ __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-// hi/lo split of an fp32 value onto 16-bit planes
+// hi/lo split of an fp32 value onto 16-bit planes: x ~= hi + lo with hi = rn16(x), lo = rn16(x - hi).
+// The two empty asm statements pin `x` and `hi` to one register each: without them hipcc (fp-contract=fast) may fold the
+// producer of x into the residual, or convert x twice with differently fused inputs, so that the stored hi and the hi the
+// residual was taken against disagree at rounding ties -- observed as rare sign-flipped lo (error = 1 ulp16 of x).
 template <typename T, int NT>
 __device__ __forceinline__ void split16(float x, T& hi, T& lo) {
+    if (NT > 1) asm volatile("" : "+v"(x));
     hi = (T)x;
-    if (NT > 1) lo = (T)(x - (float)hi);
+    if (NT > 1) {
+        asm volatile("" : "+v"(hi));
+        lo = (T)(x - (float)hi);
+    }
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -97,6 +107,8 @@ struct GemmParams {
 };
 
 void launch_gemm(int prec, const GemmParams& p, hipStream_t stream);
+// same kernel with grid.z = groups (per-group pointer advances za/zw/zbias/zout/zoutp); requires N <= 64
+void launch_gemm_grouped(int prec, const GemmParams& p, int groups, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------------------------
 // attention

@@ -1,0 +1,628 @@
+// Row-wise / bandwidth-bound kernels of the Allophant forward path on gfx950 (64-wide wavefronts):
+// input normalisation statistics, fused conv layer 0 + LayerNorm + GELU, row LayerNorm(+GELU)(+LayerNorm) with 16-bit
+// plane output, positional-conv input image, classifier-input concatenation (hidden | softmax(dependency logits)),
+// per-head log-softmax with [T,N,C] time-major output, greedy CTC decode, and the one-off weight packers.
+#include "amx_common.h"
+
+namespace amx {
+
+namespace {
+
+// ----------------------------------------------------------------------------------------------------------------
+// input normalisation (reference acoustic_model.py:762-767): statistics only; applied on the fly by conv layer 0
+// ----------------------------------------------------------------------------------------------------------------
+constexpr int STAT_CHUNKS = 64;
+
+__global__ __launch_bounds__(256) void audio_stats_kernel(const float* __restrict__ audio, const int64_t* __restrict__ lengths,
+                                                          int64_t L, double* __restrict__ partial) {
+    const int n = blockIdx.y, c = blockIdx.x;
+    int64_t per = (L + STAT_CHUNKS - 1) / STAT_CHUNKS;
+    per = (per + 3) & ~(int64_t)3;
+    int64_t lo = c * per, hi = lo + per < L ? lo + per : L;
+    const int64_t len = lengths[n];
+    const float* row = audio + (int64_t)n * L;
+    double s_all = 0, s_val = 0, q_val = 0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        double x = row[i];
+        s_all += x;
+        if (i < len) { s_val += x; q_val += x * x; }
+    }
+    __shared__ double red[3][4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s_all += __shfl_xor(s_all, o);
+        s_val += __shfl_xor(s_val, o);
+        q_val += __shfl_xor(q_val, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = s_all;
+        red[1][threadIdx.x >> 6] = s_val;
+        red[2][threadIdx.x >> 6] = q_val;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double v = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+        partial[((int64_t)n * STAT_CHUNKS + c) * 3 + threadIdx.x] = v;
+    }
+}
+
+__global__ void audio_stats_final_kernel(const double* __restrict__ partial, const int64_t* __restrict__ lengths, int N,
+                                         float* __restrict__ mean_rstd, int do_normalize) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    if (!do_normalize) { mean_rstd[2 * n] = 0.f; mean_rstd[2 * n + 1] = 1.f; return; }
+    double s_all = 0, s_val = 0, q_val = 0;
+    for (int c = 0; c < STAT_CHUNKS; ++c) {
+        s_all += partial[((int64_t)n * STAT_CHUNKS + c) * 3 + 0];
+        s_val += partial[((int64_t)n * STAT_CHUNKS + c) * 3 + 1];
+        q_val += partial[((int64_t)n * STAT_CHUNKS + c) * 3 + 2];
+    }
+    double len = (double)lengths[n];
+    double mean = s_all / len;  // the reference sums the whole padded row (zero padding contract)
+    double var = (q_val - 2.0 * mean * s_val + len * mean * mean) / len;
+    if (var < 0) var = 0;
+    mean_rstd[2 * n] = (float)mean;
+    mean_rstd[2 * n + 1] = (float)(1.0 / sqrt(var + 1e-7));
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// conv layer 0 (C_in = 1, kernel KW, stride s) + LayerNorm over channels + exact GELU  ->  16-bit planes [N*T1, C]
+// One wave per output frame, lane owns CPL consecutive channels (weights in registers), window staged in LDS.
+// HBM-bound: reads 4 B/sample once, writes 2*NT bytes per output element.
+// ----------------------------------------------------------------------------------------------------------------
+constexpr int C0_FRAMES = 64;
+
+template <typename T, int NT, int CPL, int KW>
+__global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ audio, const int64_t* __restrict__ lengths,
+                                                    const float* __restrict__ mean_rstd, int64_t L, int T1, int C, int k,
+                                                    int stride, const float* __restrict__ w, const float* __restrict__ b,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    float eps, int do_normalize, T* __restrict__ out, int64_t out_plane) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* win = (float*)smem;
+    const int n = blockIdx.y;
+    const int f0 = blockIdx.x * C0_FRAMES;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nwin = C0_FRAMES * stride + k;
+    const float mean = mean_rstd[2 * n], rstd = mean_rstd[2 * n + 1];
+    const int64_t len = lengths[n];
+    const int64_t s0 = (int64_t)f0 * stride;
+    for (int i = threadIdx.x; i < nwin; i += 256) {
+        int64_t pos = s0 + i;
+        float x = 0.f;
+        if (pos < L) {
+            x = audio[(int64_t)n * L + pos];
+            if (do_normalize) x = pos < len ? (x - mean) * rstd : 0.f;
+        }
+        win[i] = x;
+    }
+    const int c0 = lane * CPL;
+    const bool active = c0 < C;
+    float wr[CPL][KW], br[CPL], gr[CPL], be[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        int c = c0 + i;
+        bool ok = c < C;
+#pragma unroll
+        for (int j = 0; j < KW; ++j) wr[i][j] = (ok && j < k) ? w[c * k + j] : 0.f;
+        br[i] = ok ? b[c] : 0.f;
+        gr[i] = ok ? gamma[c] : 0.f;
+        be[i] = ok ? beta[c] : 0.f;
+    }
+    __syncthreads();
+    const float invC = 1.0f / (float)C;
+    for (int f = wave; f < C0_FRAMES; f += 4) {
+        const int t = f0 + f;
+        if (t >= T1) break;
+        float acc[CPL];
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) acc[i] = br[i];
+#pragma unroll
+        for (int j = 0; j < KW; ++j) {
+            float x = j < k ? win[f * stride + j] : 0.f;
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) acc[i] = fmaf(wr[i][j], x, acc[i]);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) s += (c0 + i < C) ? acc[i] : 0.f;
+        const float mu = wave_sum(s) * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            float d = acc[i] - mu;
+            q += (c0 + i < C) ? d * d : 0.f;
+        }
+        const float rs = 1.0f / sqrtf(wave_sum(q) * invC + eps);
+        T hi[CPL], lo[CPL];
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            float y = gelu_erf((acc[i] - mu) * rs * gr[i] + be[i]);
+            split16<T, NT>(y, hi[i], lo[i]);
+        }
+        if (active) {
+            T* dst = out + ((int64_t)n * T1 + t) * C + c0;
+            if constexpr (CPL == 8) {
+                typedef typename Vec8<T>::type V8;
+                V8 hv, lv;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { hv[i] = hi[i]; lv[i] = NT > 1 ? lo[i] : (T)0.f; }
+                *(V8*)dst = hv;
+                if (NT > 1) *(V8*)(dst + out_plane) = lv;
+            } else {
+#pragma unroll
+                for (int i = 0; i < CPL; ++i)
+                    if (c0 + i < C) {
+                        dst[i] = hi[i];
+                        if (NT > 1) dst[out_plane + i] = lo[i];
+                    }
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Row kernel: x[M, D] fp32 -> [LayerNorm(g1,b1) -> optional GELU] -> [LayerNorm(g2,b2)] -> planes / fp32.
+// One wave per row, D <= 1024, D % 4 == 0, row kept in registers (float4 x 4 per lane).
+// ----------------------------------------------------------------------------------------------------------------
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ x, int64_t ldx, int64_t M, int D,
+                                                      const float* __restrict__ g1, const float* __restrict__ b1, int gelu,
+                                                      const float* __restrict__ g2, const float* __restrict__ b2,
+                                                      float eps1, float eps2, T* __restrict__ out_p, int64_t out_plane,
+                                                      int64_t ldp, float* __restrict__ out_f32, int64_t ldo) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* src = x + row * ldx;
+    float4 v[4];
+    const float invD = 1.0f / (float)D;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int c = (i * 64 + lane) * 4;
+        v[i] = c < D ? *(const float4*)(src + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    auto norm = [&](const float* g, const float* b, float eps, bool act) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s += v[i].x + v[i].y + v[i].z + v[i].w;  // out-of-range entries are zero
+        const float mu = wave_sum(s) * invD;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int c = (i * 64 + lane) * 4;
+            if (c < D) {
+                float dx = v[i].x - mu, dy = v[i].y - mu, dz = v[i].z - mu, dw = v[i].w - mu;
+                q += dx * dx + dy * dy + dz * dz + dw * dw;
+            }
+        }
+        const float rs = 1.0f / sqrtf(wave_sum(q) * invD + eps);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int c = (i * 64 + lane) * 4;
+            if (c < D) {
+                float4 gg = *(const float4*)(g + c), bb = *(const float4*)(b + c);
+                float4 y;
+                y.x = (v[i].x - mu) * rs * gg.x + bb.x;
+                y.y = (v[i].y - mu) * rs * gg.y + bb.y;
+                y.z = (v[i].z - mu) * rs * gg.z + bb.z;
+                y.w = (v[i].w - mu) * rs * gg.w + bb.w;
+                if (act) { y.x = gelu_erf(y.x); y.y = gelu_erf(y.y); y.z = gelu_erf(y.z); y.w = gelu_erf(y.w); }
+                v[i] = y;
+            }
+        }
+    };
+    if (g1) norm(g1, b1, eps1, gelu != 0);
+    if (g2) norm(g2, b2, eps2, false);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int c = (i * 64 + lane) * 4;
+        if (c < D) {
+            if (out_f32) *(float4*)(out_f32 + row * ldo + c) = v[i];
+            if (out_p) {
+                T hi[4], lo[4];
+                split16<T, NT>(v[i].x, hi[0], lo[0]);
+                split16<T, NT>(v[i].y, hi[1], lo[1]);
+                split16<T, NT>(v[i].z, hi[2], lo[2]);
+                split16<T, NT>(v[i].w, hi[3], lo[3]);
+                T* dst = out_p + row * ldp + c;
+                typedef typename Vec4<T>::type V4;
+                V4 hv = {hi[0], hi[1], hi[2], hi[3]};
+                *(V4*)dst = hv;
+                if (NT > 1) {
+                    V4 lv = {lo[0], lo[1], lo[2], lo[3]};
+                    *(V4*)(dst + out_plane) = lv;
+                }
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// positional-conv input image: h[N*T, D] fp32 -> planes [G][N][Tpad][cg], zero rows in front/behind every utterance
+// ----------------------------------------------------------------------------------------------------------------
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void posconv_pack_kernel(const float* __restrict__ h, int N, int Tn, int D, int G,
+                                                           int pad_front, int Tpad, T* __restrict__ out, int64_t out_plane) {
+    const int cg = D / G;
+    const int64_t total4 = (int64_t)G * N * Tpad * cg / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        int64_t e = i * 4;
+        int ci = (int)(e % cg);
+        int64_t r = e / cg;
+        int tp = (int)(r % Tpad);
+        r /= Tpad;
+        int n = (int)(r % N);
+        int g = (int)(r / N);
+        int t = tp - pad_front;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t >= 0 && t < Tn) v = *(const float4*)(h + ((int64_t)n * Tn + t) * D + g * cg + ci);
+        T hi[4], lo[4];
+        split16<T, NT>(v.x, hi[0], lo[0]);
+        split16<T, NT>(v.y, hi[1], lo[1]);
+        split16<T, NT>(v.z, hi[2], lo[2]);
+        split16<T, NT>(v.w, hi[3], lo[3]);
+        typedef typename Vec4<T>::type V4;
+        V4 hv = {hi[0], hi[1], hi[2], hi[3]};
+        *(V4*)(out + e) = hv;
+        if (NT > 1) {
+            V4 lv = {lo[0], lo[1], lo[2], lo[3]};
+            *(V4*)(out + out_plane + e) = lv;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// classifier input: cat([hidden | softmax(dependency logits)]) as 16-bit planes, one wave per row
+// (reference acoustic_model.py:497-514)
+// ----------------------------------------------------------------------------------------------------------------
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void concat_kernel(const ConcatPart* __restrict__ parts, int n_parts,
+                                                     const float* __restrict__ logits, int64_t ld_logits, int64_t M,
+                                                     T* __restrict__ out, int64_t out_plane, int64_t ldp, int kpad) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    T* dst = out + row * ldp;
+    int kend = 0;
+    for (int pi = 0; pi < n_parts; ++pi) {
+        const ConcatPart pt = parts[pi];
+        if (pt.type == 0) {
+            const float* src = pt.src + row * pt.width;
+            for (int c = lane; c < pt.width; c += 64) {
+                T hi, lo;
+                split16<T, NT>(src[c], hi, lo);
+                dst[pt.dst_col + c] = hi;
+                if (NT > 1) dst[out_plane + pt.dst_col + c] = lo;
+            }
+        } else {
+            const float* src = logits + row * ld_logits + pt.src_col;
+            float m = -INFINITY;
+            for (int c = lane; c < pt.width; c += 64) m = fmaxf(m, src[c]);
+            m = wave_max(m);
+            float s = 0.f;
+            for (int c = lane; c < pt.width; c += 64) s += expf(src[c] - m);
+            s = wave_sum(s);
+            for (int c = lane; c < pt.width; c += 64) {
+                T hi, lo;
+                split16<T, NT>(expf(src[c] - m) / s, hi, lo);
+                dst[pt.dst_col + c] = hi;
+                if (NT > 1) dst[out_plane + pt.dst_col + c] = lo;
+            }
+        }
+        int e = pt.dst_col + pt.width;
+        kend = e > kend ? e : kend;
+    }
+    for (int c = kend + lane; c < kpad; c += 64) {
+        dst[c] = (T)0.f;
+        if (NT > 1) dst[out_plane + c] = (T)0.f;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// per-head log-softmax (reference estimator.py:1041-1045), batch-major logits -> time-major [T,N,C] outputs
+// ----------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void logsoftmax_out_kernel(const OutDesc* __restrict__ descs, int n_out,
+                                                             const float* __restrict__ logits, int64_t ld, int N, int T,
+                                                             int log_probs, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // row = n*T + t
+    if (row >= (int64_t)N * T) return;
+    const int n = (int)(row / T), t = (int)(row % T);
+    const float* src_row = logits + row * ld;
+    for (int o = 0; o < n_out; ++o) {
+        const OutDesc d = descs[o];
+        const float* src = src_row + d.col;
+        float* dst = out + d.out_off + ((int64_t)t * N + n) * d.C;
+        float lse = 0.f;
+        if (log_probs) {
+            float m = -INFINITY;
+            for (int c = lane; c < d.C; c += 64) m = fmaxf(m, src[c]);
+            m = wave_max(m);
+            float s = 0.f;
+            for (int c = lane; c < d.C; c += 64) s += expf(src[c] - m);
+            s = wave_sum(s);
+            lse = m + logf(s);
+        }
+        for (int c = lane; c < d.C; c += 64) dst[c] = src[c] - lse;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// greedy CTC (reference predictions.py:194-207): argmax, collapse repeats, drop blank 0, 1-based start timesteps,
+// score = sum of the per-frame maxima.  One block per (output, utterance).
+// ----------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void greedy_ctc_kernel(const OutDesc* __restrict__ descs, const float* __restrict__ out,
+                                                         const int* __restrict__ frame_len, int N, int T,
+                                                         int64_t* __restrict__ tokens, int64_t* __restrict__ timesteps,
+                                                         int* __restrict__ counts, float* __restrict__ scores) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* idx = (int*)smem;          // [T]
+    int* scan = idx + T;            // [256]
+    float* fred = (float*)(scan + 256);  // [256]
+    const int o = blockIdx.y, n = blockIdx.x;
+    const OutDesc d = descs[o];
+    const int len = frame_len[n] < T ? frame_len[n] : T;
+    const float* base = out + d.out_off;
+    float score = 0.f;
+    for (int t = threadIdx.x; t < len; t += 256) {
+        const float* p = base + ((int64_t)t * N + n) * d.C;
+        float best = p[0];
+        int bi = 0;
+        for (int c = 1; c < d.C; ++c) {
+            float v = p[c];
+            if (v > best) { best = v; bi = c; }
+        }
+        idx[t] = bi;
+        score += best;
+    }
+    fred[threadIdx.x] = score;
+    __syncthreads();
+    // contiguous segment per thread
+    const int seg = (len + 255) / 256;
+    const int lo = threadIdx.x * seg, hi = lo + seg < len ? lo + seg : len;
+    int cnt = 0;
+    for (int t = lo; t < hi; ++t) {
+        bool start = t == 0 || idx[t] != idx[t - 1];
+        cnt += (start && idx[t] != 0) ? 1 : 0;
+    }
+    scan[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        int v = threadIdx.x >= off ? scan[threadIdx.x - off] : 0;
+        float f = threadIdx.x + off < 256 ? fred[threadIdx.x + off] : 0.f;
+        __syncthreads();
+        scan[threadIdx.x] += v;
+        if ((threadIdx.x & (2 * off - 1)) == 0) fred[threadIdx.x] += f;
+        __syncthreads();
+    }
+    int pos = scan[threadIdx.x] - cnt;  // exclusive prefix
+    int64_t* tok = tokens + ((int64_t)o * N + n) * T;
+    int64_t* ts = timesteps + ((int64_t)o * N + n) * T;
+    for (int t = lo; t < hi; ++t) {
+        bool start = t == 0 || idx[t] != idx[t - 1];
+        if (start && idx[t] != 0) {
+            tok[pos] = idx[t];
+            ts[pos] = t + 1;
+            ++pos;
+        }
+    }
+    if (threadIdx.x == 255) counts[o * N + n] = scan[255];
+    if (threadIdx.x == 0) scores[o * N + n] = fred[0];
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// weight packers
+// ----------------------------------------------------------------------------------------------------------------
+template <typename T, int NT>
+__global__ void pack_matrix_kernel(const float* __restrict__ src, int rows, int cols, int64_t srs, int64_t scs, float scale,
+                                   T* __restrict__ dst, int64_t dst_plane, int64_t ldd, int cols_pad) {
+    int64_t total = (int64_t)rows * cols_pad;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int r = (int)(i / cols_pad), c = (int)(i % cols_pad);
+        float v = c < cols ? src[r * srs + c * scs] * scale : 0.f;
+        T hi, lo;
+        split16<T, NT>(v, hi, lo);
+        dst[r * ldd + c] = hi;
+        if (NT > 1) dst[dst_plane + r * ldd + c] = lo;
+    }
+}
+
+template <typename T, int NT>
+__global__ void pack_conv_w_kernel(const float* __restrict__ src, int Co, int Ci, int k, T* __restrict__ dst,
+                                   int64_t dst_plane) {
+    // dst[co][j*Ci + ci] = src[co][ci][j]
+    int64_t total = (int64_t)Co * Ci * k;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int ci = (int)(i % Ci);
+        int64_t r = i / Ci;
+        int j = (int)(r % k);
+        int co = (int)(r / k);
+        T hi, lo;
+        split16<T, NT>(src[((int64_t)co * Ci + ci) * k + j], hi, lo);
+        dst[i] = hi;
+        if (NT > 1) dst[dst_plane + i] = lo;
+    }
+}
+
+__global__ __launch_bounds__(256) void posconv_norm_kernel(const float* __restrict__ v, int64_t rows /*D*cg*/, int k,
+                                                           float* __restrict__ norm) {
+    // weight_norm(dim=2): one norm per kernel tap over dims (0,1)
+    const int tap = blockIdx.x;
+    double s = 0;
+    for (int64_t r = threadIdx.x; r < rows; r += 256) {
+        double x = v[r * k + tap];
+        s += x * x;
+    }
+    __shared__ double red[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) norm[tap] = (float)sqrt(red[0] + red[1] + red[2] + red[3]);
+}
+
+template <typename T, int NT>
+__global__ void pack_posconv_w_kernel(const float* __restrict__ g, const float* __restrict__ v, const float* __restrict__ norm,
+                                      int D, int cg, int k, T* __restrict__ dst, int64_t dst_plane) {
+    // dst[grp][co][tap*cg + ci] = v[grp*cg + co][ci][tap] * (g[tap] / norm[tap])
+    int64_t total = (int64_t)D * cg * k;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int ci = (int)(i % cg);
+        int64_t r = i / cg;
+        int tap = (int)(r % k);
+        int co_all = (int)(r / k);  // grp*cg + co
+        float w = v[((int64_t)co_all * cg + ci) * k + tap] * (g[tap] / norm[tap]);
+        T hi, lo;
+        split16<T, NT>(w, hi, lo);
+        dst[i] = hi;
+        if (NT > 1) dst[dst_plane + i] = lo;
+    }
+}
+
+template <typename T, int NT>
+__global__ void compose_kernel(const float* __restrict__ emb, int E, const int64_t* __restrict__ idx, int P1, int F,
+                               float* __restrict__ composed, T* __restrict__ dst, int64_t dst_plane, int64_t ldd) {
+    // EmbeddingBag(mode="sum") per phone (reference acoustic_model.py:219-232); negative index = unused slot
+    int64_t total = (int64_t)P1 * E;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int e = (int)(i % E), p = (int)(i / E);
+        float s = 0.f;
+        for (int f = 0; f < F; ++f) {
+            int64_t r = idx[(int64_t)p * F + f];
+            if (r >= 0) s += emb[r * E + e];
+        }
+        composed[i] = s;
+        T hi, lo;
+        split16<T, NT>(s, hi, lo);
+        dst[(int64_t)p * ldd + e] = hi;
+        if (NT > 1) dst[dst_plane + (int64_t)p * ldd + e] = lo;
+    }
+}
+
+__global__ void scale_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t n, float scale) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = src[i] * scale;
+}
+
+inline int grid_for(int64_t n, int block = 256, int cap = 8192) {
+    int64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    return (int)(g < cap ? g : cap);
+}
+
+}  // namespace
+
+#define AMX_DISPATCH(prec, CALL)                                   \
+    switch (prec) {                                                \
+        case PREC_BF16: { typedef bf16 T16; constexpr int NT = 1; CALL; } break;   \
+        case PREC_F16: { typedef f16 T16; constexpr int NT = 1; CALL; } break;     \
+        case PREC_BF16X3: { typedef bf16 T16; constexpr int NT = 2; CALL; } break; \
+        default: { typedef f16 T16; constexpr int NT = 2; CALL; } break;           \
+    }
+
+void launch_audio_stats(const float* audio, const int64_t* lengths, int N, int64_t L, double* partial, float* mean_rstd,
+                        int do_normalize, hipStream_t s) {
+    if (do_normalize) hipLaunchKernelGGL(audio_stats_kernel, dim3(STAT_CHUNKS, N), dim3(256), 0, s, audio, lengths, L, partial);
+    hipLaunchKernelGGL(audio_stats_final_kernel, dim3((N + 63) / 64), dim3(64), 0, s, partial, lengths, N, mean_rstd,
+                       do_normalize);
+}
+
+template <typename T, int NT, int KW>
+static void conv0_launch_cpl(const float* audio, const int64_t* lengths, const float* mean_rstd, int N, int64_t L, int T1,
+                             int C, int k, int stride, const float* w, const float* b, const float* gamma,
+                             const float* beta, float eps, int do_normalize, void* out, int64_t out_plane, hipStream_t s) {
+    dim3 grid((T1 + C0_FRAMES - 1) / C0_FRAMES, N);
+    size_t lds = (size_t)(C0_FRAMES * stride + k) * sizeof(float);
+    int cpl = C >= 64 ? C / 64 : 1;
+#define C0_GO(CPL)                                                                                                  \
+    hipLaunchKernelGGL((conv0_kernel<T, NT, CPL, KW>), grid, dim3(256), lds, s, audio, lengths, mean_rstd, L, T1, C, k, \
+                       stride, w, b, gamma, beta, eps, do_normalize, (T*)out, out_plane)
+    if (cpl == 8) C0_GO(8);
+    else if (cpl == 4) C0_GO(4);
+    else if (cpl == 2) C0_GO(2);
+    else C0_GO(1);
+#undef C0_GO
+}
+
+void launch_conv0(int prec, const float* audio, const int64_t* lengths, const float* mean_rstd, int N, int64_t L, int T1,
+                  int C, int k, int stride, const float* w, const float* b, const float* gamma, const float* beta,
+                  float eps, int do_normalize, void* out, int64_t out_plane, hipStream_t s) {
+    if (k == 10) {
+        AMX_DISPATCH(prec, (conv0_launch_cpl<T16, NT, 10>(audio, lengths, mean_rstd, N, L, T1, C, k, stride, w, b, gamma, beta,
+                                                         eps, do_normalize, out, out_plane, s)));
+    } else {
+        AMX_DISPATCH(prec, (conv0_launch_cpl<T16, NT, 16>(audio, lengths, mean_rstd, N, L, T1, C, k, stride, w, b, gamma, beta,
+                                                         eps, do_normalize, out, out_plane, s)));
+    }
+}
+
+void launch_rownorm(int prec, const float* x, int64_t ldx, int64_t M, int D, const float* gamma1, const float* beta1,
+                    int gelu, const float* gamma2, const float* beta2, float eps1, float eps2, void* out_p,
+                    int64_t out_plane, int64_t ldp, float* out_f32, int64_t ldo, hipStream_t s) {
+    dim3 grid((unsigned)((M + 3) / 4));
+    AMX_DISPATCH(prec, hipLaunchKernelGGL((rownorm_kernel<T16, NT>), grid, dim3(256), 0, s, x, ldx, M, D, gamma1, beta1, gelu,
+                                          gamma2, beta2, eps1, eps2, (T16*)out_p, out_plane, ldp, out_f32, ldo));
+}
+
+void launch_posconv_pack(int prec, const float* h, int N, int T, int D, int G, int pad_front, int Tpad, void* out,
+                         int64_t out_plane, hipStream_t s) {
+    int64_t total4 = (int64_t)N * Tpad * D / 4;
+    AMX_DISPATCH(prec, hipLaunchKernelGGL((posconv_pack_kernel<T16, NT>), dim3(grid_for(total4)), dim3(256), 0, s, h, N, T, D,
+                                          G, pad_front, Tpad, (T16*)out, out_plane));
+}
+
+void launch_concat(int prec, const ConcatPart* parts_dev, int n_parts, const float* logits, int64_t ld_logits, int64_t M,
+                   void* out, int64_t out_plane, int64_t ldp, int kpad, hipStream_t s) {
+    dim3 grid((unsigned)((M + 3) / 4));
+    AMX_DISPATCH(prec, hipLaunchKernelGGL((concat_kernel<T16, NT>), grid, dim3(256), 0, s, parts_dev, n_parts, logits,
+                                          ld_logits, M, (T16*)out, out_plane, ldp, kpad));
+}
+
+void launch_logsoftmax_out(const OutDesc* descs_dev, int n_out, const float* logits, int64_t ld, int N, int T,
+                           int log_probs, float* out, hipStream_t s) {
+    int64_t M = (int64_t)N * T;
+    hipLaunchKernelGGL(logsoftmax_out_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, descs_dev, n_out, logits, ld,
+                       N, T, log_probs, out);
+}
+
+void launch_greedy_ctc(const OutDesc* descs_dev, int n_out, const float* out, const int* frame_len, int N, int T,
+                       int64_t* tokens, int64_t* timesteps, int* counts, float* scores, hipStream_t s) {
+    size_t lds = (size_t)T * sizeof(int) + 256 * sizeof(int) + 256 * sizeof(float);
+    hipLaunchKernelGGL(greedy_ctc_kernel, dim3(N, n_out), dim3(256), lds, s, descs_dev, out, frame_len, N, T, tokens,
+                       timesteps, counts, scores);
+}
+
+void launch_pack_matrix(int prec, const float* src, int rows, int cols, int64_t src_row_stride, int64_t src_col_stride,
+                        float scale, void* dst, int64_t dst_plane, int64_t ldd, int cols_pad, hipStream_t s) {
+    int64_t total = (int64_t)rows * cols_pad;
+    AMX_DISPATCH(prec, hipLaunchKernelGGL((pack_matrix_kernel<T16, NT>), dim3(grid_for(total)), dim3(256), 0, s, src, rows,
+                                          cols, src_row_stride, src_col_stride, scale, (T16*)dst, dst_plane, ldd, cols_pad));
+}
+
+void launch_pack_conv_w(int prec, const float* src, int Co, int Ci, int k, void* dst, int64_t dst_plane, hipStream_t s) {
+    int64_t total = (int64_t)Co * Ci * k;
+    AMX_DISPATCH(prec, hipLaunchKernelGGL((pack_conv_w_kernel<T16, NT>), dim3(grid_for(total)), dim3(256), 0, s, src, Co, Ci, k,
+                                          (T16*)dst, dst_plane));
+}
+
+void launch_pack_posconv_w(int prec, const float* g, const float* v, int D, int cg, int k, float* norm_scratch, void* dst,
+                           int64_t dst_plane, hipStream_t s) {
+    hipLaunchKernelGGL(posconv_norm_kernel, dim3(k), dim3(256), 0, s, v, (int64_t)D * cg, k, norm_scratch);
+    int64_t total = (int64_t)D * cg * k;
+    AMX_DISPATCH(prec, hipLaunchKernelGGL((pack_posconv_w_kernel<T16, NT>), dim3(grid_for(total)), dim3(256), 0, s, g, v,
+                                          norm_scratch, D, cg, k, (T16*)dst, dst_plane));
+}
+
+void launch_compose(int prec, const float* emb, int E, const int64_t* idx, int P1, int F, float* composed_f32, void* dst,
+                    int64_t dst_plane, int64_t ldd, hipStream_t s) {
+    int64_t total = (int64_t)P1 * E;
+    AMX_DISPATCH(prec, hipLaunchKernelGGL((compose_kernel<T16, NT>), dim3(grid_for(total)), dim3(256), 0, s, emb, E, idx, P1, F,
+                                          composed_f32, (T16*)dst, dst_plane, ldd));
+}
+
+void launch_scale_copy(const float* src, float* dst, int64_t n, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(scale_copy_kernel, dim3(grid_for(n)), dim3(256), 0, s, src, dst, n, scale);
+}
+
+}  // namespace amx

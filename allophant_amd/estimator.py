@@ -1,0 +1,348 @@
+"""Drop-in façade over ``liballophant_amx``: the reference's ``Estimator`` / ``Batch`` / ``Predictions`` names, shapes and
+error behaviour for the prediction path.
+
+Mirrors (reference file:line):
+  * ``Batch``                allophant/dataset_processing.py:49-85
+  * ``Predictions``          allophant/network/acoustic_model.py:908-926
+  * ``Estimator.predict``    allophant/estimator.py:1035-1046
+  * ``Estimator.restore``    allophant/estimator.py:1085-1126 (checkpoint dict schema estimator.py:199-249)
+  * ``GreedyCTCDecoder``     allophant/predictions.py:189-207
+
+PyTorch is used only as plumbing (device memory for inputs/outputs, the current HIP stream); all arithmetic happens in the
+HIP kernels behind the C ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+from dataclasses import dataclass
+from typing import Any, Dict, List, NamedTuple, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+from . import lib as _lib
+from . import spec as _spec
+
+
+@dataclass
+class Batch:
+    """``Batch(audio_features [N, L] f32 zero right-padded, lengths [N] i64 samples, language_ids [N])``."""
+
+    audio_features: Tensor
+    lengths: Tensor
+    language_ids: Tensor
+
+    def pin_memory(self):
+        self.audio_features = self.audio_features.pin_memory()
+        self.lengths = self.lengths.pin_memory()
+        self.language_ids = self.language_ids.pin_memory()
+        return self
+
+    def to(self, device, non_blocking: bool = False, copy: bool = False):
+        return self.__class__(
+            self.audio_features.to(device, non_blocking=non_blocking, copy=copy),
+            self.lengths.to(device, non_blocking=non_blocking, copy=copy),
+            self.language_ids.to(device, non_blocking=non_blocking, copy=copy),
+        )
+
+    def cuda(self, non_blocking: bool = False, copy: bool = False):
+        return self.to("cuda", non_blocking, copy)
+
+    def size(self) -> int:
+        return len(self)
+
+    def __len__(self) -> int:
+        return self.lengths.numel()
+
+    def __repr__(self) -> str:
+        return "{}(Features: ({}; {}))".format(self.__class__.__name__, self.audio_features.shape, self.audio_features.dtype)
+
+
+@dataclass
+class Predictions:
+    """``outputs``: name -> [T, N, C] (log-)probabilities, time-major; ``lengths``: [N] int64 output frames."""
+
+    outputs: Dict[str, Tensor]
+    lengths: Tensor
+    # flat device buffer the outputs are views of (kept for the on-device greedy decoder); not part of the reference API
+    _flat: Optional[Tensor] = dataclasses.field(default=None, repr=False, compare=False)
+    _geometry: Optional[Tuple[int, int]] = dataclasses.field(default=None, repr=False, compare=False)
+
+    def __len__(self) -> int:
+        return len(self.lengths)
+
+    def task_count(self) -> int:
+        return len(self.outputs)
+
+
+class CTCHypothesis(NamedTuple):
+    """Field-compatible with ``torchaudio.models.decoder.CTCHypothesis`` as used by the reference decoder."""
+
+    tokens: Tensor
+    words: List[str]
+    score: float
+    timesteps: Tensor
+
+
+def _spec_to_structs(spec: Dict[str, Any], precision: str):
+    cfg = _lib.AmxConfig()
+    cfg.abi_version = _lib.AMX_ABI_VERSION
+    n = len(spec["conv_kernel"])
+    if n > _lib.AMX_MAX_CONV:
+        raise ValueError("too many conv layers")
+    cfg.n_conv = n
+    cfg.conv_dim = spec["conv_dim"]
+    for i in range(n):
+        cfg.conv_kernel[i] = spec["conv_kernel"][i]
+        cfg.conv_stride[i] = spec["conv_stride"][i]
+    cfg.hidden, cfg.layers, cfg.heads, cfg.ffn = spec["hidden"], spec["layers"], spec["heads"], spec["ffn"]
+    cfg.pos_kernel, cfg.pos_groups = spec["pos_kernel"], spec["pos_groups"]
+    cfg.eps = spec["eps"]
+    cfg.do_normalize = int(spec.get("do_normalize", True))
+    cfg.dependency_blanks = int(spec.get("dependency_blanks", True))
+    cfg.embedding_size = int(spec.get("embedding_size") or 0)
+    cfg.allophone_layer = int(bool(spec.get("allophone_layer", False)))
+    if precision not in _lib.PRECISIONS:
+        raise ValueError(f"unknown precision {precision!r}; expected one of {sorted(_lib.PRECISIONS)}")
+    cfg.precision = _lib.PRECISIONS[precision]
+
+    classes = spec["classes"]
+    index = {c["name"]: i for i, c in enumerate(classes)}
+    descs = (_lib.AmxClassDesc * len(classes))()
+    for i, c in enumerate(classes):
+        if len(c["name"].encode()) >= _lib.AMX_NAME_LEN:
+            raise ValueError(f"classifier name too long: {c['name']}")
+        descs[i].name = c["name"].encode()
+        descs[i].size = c["size"]
+        composed = c["name"] == _spec.PHONEME and cfg.embedding_size
+        allophone = c["name"] == _spec.PHONEME and cfg.allophone_layer
+        out_classes = spec.get("shared_phones", c["size"]) if allophone else c["size"]
+        descs[i].out_features = cfg.embedding_size if composed else out_classes + _spec.BLANK_OFFSET
+        deps = c["dependencies"]
+        if len(deps) > _lib.AMX_MAX_DEPS:
+            raise ValueError("too many dependencies")
+        descs[i].n_deps = len(deps)
+        for j, d in enumerate(deps):
+            m = _spec.OUTPUT_PATTERN.match(d)
+            if m:
+                descs[i].deps[j] = _lib.DEP_OUTPUT if m.group(1) is None else _lib.dep_output_layer(int(m.group(1)))
+            else:
+                if d not in index:
+                    raise ValueError(f"unknown dependency {d!r}")
+                descs[i].deps[j] = index[d]
+    return cfg, descs
+
+
+class Estimator:
+    """Prediction-side replacement of the reference ``Estimator`` running on one MI355X.
+
+    ``precision``: ``"f16x3"`` (default; fp32-grade split-precision MFMA, meets the 1e-3 logit gate), ``"bf16x3"``,
+    ``"f16"`` or ``"bf16"`` (single-plane throughput modes; error measured in tests/ and DESIGN.md).
+    """
+
+    def __init__(self, spec: Dict[str, Any], state_dict: Dict[str, Tensor], device: str | torch.device = "cuda:0",
+                 precision: str = "f16x3"):
+        _spec.validate(spec)
+        self._spec = spec
+        self._lib = _lib.load()
+        self._device = torch.device(device)
+        if self._device.type != "cuda":
+            raise RuntimeError("allophant_amd runs on an MI355X only (device must be cuda:N); there is no CPU fallback")
+        self._index = self._device.index if self._device.index is not None else torch.cuda.current_device()
+        self._precision = precision
+        cfg, descs = _spec_to_structs(spec, precision)
+        keep = []
+        tensors = (_lib.AmxTensor * len(state_dict))()
+        for i, (k, v) in enumerate(state_dict.items()):
+            t = v.detach().to("cpu", torch.float32).contiguous()
+            keep.append(t)
+            tensors[i].name = k.encode()
+            tensors[i].data = C.cast(t.data_ptr(), C.POINTER(C.c_float))
+            tensors[i].numel = t.numel()
+        handle = C.c_void_p()
+        code = self._lib.amx_create(C.byref(handle), self._index, C.byref(cfg), descs, len(descs), tensors, len(state_dict))
+        _lib.check(self._lib, None, code)
+        self._handle = handle
+        self._classes = [c["name"] for c in spec["classes"]]
+        self._inventory: Optional[Tensor] = None
+        cats = spec.get("composition_categories")
+        self._category_offsets = None
+        if spec.get("embedding_size"):
+            if cats is None:
+                raise ValueError("composition models need `composition_categories` (number of values per feature)")
+            self._category_offsets = torch.tensor([1] + list(cats), dtype=torch.int64).cumsum(0)[:-1].contiguous()
+
+    # -- reference-compatible surface ------------------------------------------------------------------------------
+    @property
+    def classes(self) -> List[str]:
+        return self._classes
+
+    @property
+    def precision(self) -> str:
+        return self._precision
+
+    @property
+    def device_bytes(self) -> int:
+        return int(self._lib.amx_device_bytes(self._handle))
+
+    @classmethod
+    def restore(cls, checkpoint_or_path, device: str = "cuda:0", precision: str = "f16x3"):
+        """Builds an estimator from a checkpoint dict in the reference ``Checkpoint`` schema (estimator.py:199-249) or a
+        path to one saved with ``torch.save``.  Returns ``(estimator, attribute_indexer)`` like the reference; the
+        indexer slot is ``None`` (the Allophoible table needed to rebuild it is not reachable offline) -- pass
+        ``composition_feature_matrix`` tensors explicitly as ``target_feature_indices``."""
+        from .checkpoint import spec_from_checkpoint
+
+        if not isinstance(checkpoint_or_path, dict):
+            checkpoint_or_path = torch.load(checkpoint_or_path, map_location="cpu", weights_only=True)
+        spec = spec_from_checkpoint(checkpoint_or_path)
+        return cls(spec, checkpoint_or_path["model_state"], device, precision), None
+
+    def _set_inventory(self, tfi: Tensor) -> None:
+        tfi_cpu = tfi.detach().to("cpu", torch.int64).contiguous()
+        if self._inventory is not None and self._inventory.shape == tfi_cpu.shape and torch.equal(self._inventory, tfi_cpu):
+            return
+        if tfi_cpu.dim() != 2 or tfi_cpu.shape[1] != self._category_offsets.numel():
+            raise ValueError(
+                f"target_feature_indices must be [phones, {self._category_offsets.numel()}] (composition_feature_matrix)")
+        code = self._lib.amx_set_inventory(
+            self._handle, C.cast(tfi_cpu.data_ptr(), C.POINTER(C.c_int64)), tfi_cpu.shape[0], tfi_cpu.shape[1],
+            C.cast(self._category_offsets.data_ptr(), C.POINTER(C.c_int64)))
+        _lib.check(self._lib, self._handle, code)
+        self._inventory = tfi_cpu
+
+    def predict(self, batch: Batch, target_feature_indices: Optional[Tensor] = None, log_probabilities: bool = True,
+                _keep_hidden: bool = False) -> Predictions:
+        """``Estimator.predict`` (reference estimator.py:1035-1046)."""
+        if self._spec.get("embedding_size"):
+            if target_feature_indices is None:
+                if self._inventory is None:
+                    raise ValueError(
+                        "composition models need `target_feature_indices`: the training inventory table is a "
+                        "non-persistent buffer upstream (acoustic_model.py:214-221) and is not part of a checkpoint")
+            else:
+                self._set_inventory(target_feature_indices)
+        audio = batch.audio_features
+        if audio.dim() != 2:
+            raise ValueError("audio_features must be [N, L]")
+        audio = audio.to(self._device, torch.float32).contiguous()
+        lengths = batch.lengths.detach().to("cpu", torch.int64).contiguous()
+        N, L = audio.shape
+        if lengths.numel() != N:
+            raise ValueError("lengths must have one entry per utterance")
+        with torch.cuda.device(self._device):
+            n_out = C.c_int()
+            T = C.c_int64()
+            total = C.c_int64()
+            code = self._lib.amx_output_layout(self._handle, N, L, None, C.byref(n_out), C.byref(T), C.byref(total))
+            _lib.check(self._lib, self._handle, code)
+            descs = (_lib.AmxOutputDesc * n_out.value)()
+            code = self._lib.amx_output_layout(self._handle, N, L, descs, C.byref(n_out), C.byref(T), C.byref(total))
+            _lib.check(self._lib, self._handle, code)
+            flat = torch.empty(total.value, dtype=torch.float32, device=self._device)
+            out_lengths = torch.empty(N, dtype=torch.int64)
+            flags = 0 if log_probabilities else _lib.FLAG_RAW_LOGITS
+            if _keep_hidden:
+                flags |= _lib.FLAG_KEEP_HIDDEN
+            stream = torch.cuda.current_stream(self._device).cuda_stream
+            code = self._lib.amx_forward(
+                self._handle, C.c_void_p(audio.data_ptr()), C.cast(lengths.data_ptr(), C.POINTER(C.c_int64)), N, L,
+                C.c_void_p(flat.data_ptr()), C.cast(out_lengths.data_ptr(), C.POINTER(C.c_int64)), flags,
+                C.c_void_p(stream))
+            _lib.check(self._lib, self._handle, code)
+            # keep `audio` alive until the asynchronous kernels have consumed it
+            flat.record_stream(torch.cuda.current_stream(self._device))
+            audio.record_stream(torch.cuda.current_stream(self._device))
+        self._geom = (N, int(T.value))
+        outputs: Dict[str, Tensor] = {}
+        for d in descs:
+            c = d.classes
+            outputs[d.name.decode()] = flat[d.offset: d.offset + T.value * N * c].view(T.value, N, c)
+        return Predictions(outputs, out_lengths.to(batch.lengths.device), flat, (N, L))
+
+    def greedy_decode(self, predictions: Predictions) -> Dict[str, List[List[CTCHypothesis]]]:
+        """On-device ``GreedyCTCDecoder`` over every output of ``predictions`` (reference predictions.py:194-207 applied
+        per classifier as in run.py:767-774).  Only token ids / timesteps / scores cross PCIe."""
+        if predictions._flat is None or predictions._geometry is None:
+            raise ValueError("predictions were not produced by this estimator")
+        N, L = predictions._geometry
+        names = list(predictions.outputs.keys())
+        T = next(iter(predictions.outputs.values())).shape[0]
+        with torch.cuda.device(self._device):
+            tokens = torch.empty(len(names), N, T, dtype=torch.int64, device=self._device)
+            timesteps = torch.empty_like(tokens)
+            counts = torch.empty(len(names), N, dtype=torch.int32, device=self._device)
+            scores = torch.empty(len(names), N, dtype=torch.float32, device=self._device)
+            stream = torch.cuda.current_stream(self._device).cuda_stream
+            code = self._lib.amx_greedy_ctc(
+                self._handle, C.c_void_p(predictions._flat.data_ptr()), N, L, C.c_void_p(tokens.data_ptr()),
+                C.c_void_p(timesteps.data_ptr()), C.c_void_p(counts.data_ptr()), C.c_void_p(scores.data_ptr()),
+                C.c_void_p(stream))
+            _lib.check(self._lib, self._handle, code)
+            counts_h = counts.cpu()
+            scores_h = scores.cpu()
+            tokens_h = tokens.cpu()
+            timesteps_h = timesteps.cpu()
+        result: Dict[str, List[List[CTCHypothesis]]] = {}
+        for o, name in enumerate(names):
+            hyps = []
+            for n in range(N):
+                k = int(counts_h[o, n])
+                hyps.append([CTCHypothesis(tokens_h[o, n, :k].clone(), [], float(scores_h[o, n]), timesteps_h[o, n, :k].clone())])
+            result[name] = hyps
+        return result
+
+    def debug_fetch(self, what: str, index: int = 0) -> Tensor:
+        """Test hook: intermediates of the last ``predict(..., _keep_hidden=True)`` as CPU fp32 tensors."""
+        code_of = {"conv": 0, "hidden": 1, "logits": 2}
+        n_t = self._last_geometry()
+        if what == "conv":
+            shape = (n_t[0], n_t[1], self._spec["conv_dim"])
+        elif what == "hidden":
+            shape = (n_t[0], n_t[1], self._spec["hidden"])
+        else:
+            shape = None
+        ld = C.c_int64(0)
+        if shape is None:
+            buf = torch.empty(n_t[0] * n_t[1] * 4096, dtype=torch.float32)
+        else:
+            buf = torch.empty(shape, dtype=torch.float32)
+        code = self._lib.amx_debug_fetch(self._handle, code_of[what], index, C.c_void_p(buf.data_ptr()), buf.numel(), C.byref(ld))
+        _lib.check(self._lib, self._handle, code)
+        if shape is None:
+            return buf[: n_t[0] * n_t[1] * ld.value].view(n_t[0] * n_t[1], ld.value)
+        return buf
+
+    def _last_geometry(self) -> Tuple[int, int]:
+        if not hasattr(self, "_geom"):
+            raise RuntimeError("no forward pass yet")
+        return self._geom
+
+    def synchronize(self) -> None:
+        stream = torch.cuda.current_stream(self._device).cuda_stream
+        _lib.check(self._lib, self._handle, self._lib.amx_synchronize(self._handle, C.c_void_p(stream)))
+
+    def close(self) -> None:
+        if getattr(self, "_handle", None):
+            self._lib.amx_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GreedyCTCDecoder:
+    """API-compatible stand-in for the reference ``GreedyCTCDecoder`` (predictions.py:189-207) bound to an estimator: call
+    it with the ``Predictions`` object to decode on the device, or use ``Estimator.greedy_decode`` directly."""
+
+    def __init__(self, estimator: Estimator, blank_index: int = 0):
+        if blank_index != 0:
+            raise ValueError("the CTC blank is index 0 (config.py:555)")
+        self._estimator = estimator
+
+    def __call__(self, predictions: Predictions) -> Dict[str, List[List[CTCHypothesis]]]:
+        return self._estimator.greedy_decode(predictions)

@@ -1,0 +1,114 @@
+"""ctypes binding of ``liballophant_amx.so`` (C ABI declared in ``include/allophant_amx.h``).
+
+There is deliberately no fallback: if the HIP library has not been built (``python -c 'import __graft_entry__ as g;
+g.build()'`` or ``make -C allophant_amd/csrc``) every compute entry point raises ``RuntimeError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+AMX_ABI_VERSION = 1
+AMX_MAX_CONV = 8
+AMX_MAX_DEPS = 64
+AMX_NAME_LEN = 48
+
+AMX_OK, AMX_EINVAL, AMX_EHIP, AMX_ESTATE, AMX_ENOMEM = 0, -1, -2, -3, -4
+PRECISIONS = {"bf16": 0, "f16": 1, "bf16x3": 2, "f16x3": 3}
+FLAG_HOST_IO, FLAG_RAW_LOGITS, FLAG_KEEP_HIDDEN = 1, 2, 4
+DEP_OUTPUT = -1
+
+LIB_NAME = "liballophant_amx.so"
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+
+# every symbol include/allophant_amx.h declares
+EXPORTS = [
+    "amx_create", "amx_destroy", "amx_last_error", "amx_set_inventory", "amx_output_layout", "amx_forward",
+    "amx_synchronize", "amx_greedy_ctc", "amx_debug_fetch", "amx_device_bytes",
+]
+
+
+def dep_output_layer(i: int) -> int:
+    return -2 - i
+
+
+class AmxConfig(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("n_conv", C.c_int32), ("conv_dim", C.c_int32),
+        ("conv_kernel", C.c_int32 * AMX_MAX_CONV), ("conv_stride", C.c_int32 * AMX_MAX_CONV),
+        ("hidden", C.c_int32), ("layers", C.c_int32), ("heads", C.c_int32), ("ffn", C.c_int32),
+        ("pos_kernel", C.c_int32), ("pos_groups", C.c_int32), ("eps", C.c_float), ("do_normalize", C.c_int32),
+        ("dependency_blanks", C.c_int32), ("embedding_size", C.c_int32), ("allophone_layer", C.c_int32),
+        ("precision", C.c_int32),
+    ]
+
+
+class AmxClassDesc(C.Structure):
+    _fields_ = [
+        ("name", C.c_char * AMX_NAME_LEN), ("size", C.c_int32), ("out_features", C.c_int32), ("n_deps", C.c_int32),
+        ("deps", C.c_int32 * AMX_MAX_DEPS),
+    ]
+
+
+class AmxTensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.POINTER(C.c_float)), ("numel", C.c_int64)]
+
+
+class AmxOutputDesc(C.Structure):
+    _fields_ = [("name", C.c_char * AMX_NAME_LEN), ("classes", C.c_int32), ("offset", C.c_int64)]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Loads the shared library and declares the prototypes; raises if it is missing (no CPU fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build the HIP extension first (make -C allophant_amd/csrc, or "
+            "__graft_entry__.build()). allophant_amd has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
+    lib.amx_create.argtypes = [C.POINTER(vp), i32, C.POINTER(AmxConfig), C.POINTER(AmxClassDesc), i32,
+                               C.POINTER(AmxTensor), i32]
+    lib.amx_create.restype = i32
+    lib.amx_destroy.argtypes = [vp]
+    lib.amx_destroy.restype = i32
+    lib.amx_last_error.argtypes = [vp]
+    lib.amx_last_error.restype = C.c_char_p
+    lib.amx_set_inventory.argtypes = [vp, C.POINTER(i64), i32, i32, C.POINTER(i64)]
+    lib.amx_set_inventory.restype = i32
+    lib.amx_output_layout.argtypes = [vp, i32, i64, C.POINTER(AmxOutputDesc), C.POINTER(i32), C.POINTER(i64),
+                                      C.POINTER(i64)]
+    lib.amx_output_layout.restype = i32
+    lib.amx_forward.argtypes = [vp, vp, C.POINTER(i64), i32, i64, vp, C.POINTER(i64), C.c_uint32, vp]
+    lib.amx_forward.restype = i32
+    lib.amx_synchronize.argtypes = [vp, vp]
+    lib.amx_synchronize.restype = i32
+    lib.amx_greedy_ctc.argtypes = [vp, vp, i32, i64, vp, vp, vp, vp, vp]
+    lib.amx_greedy_ctc.restype = i32
+    lib.amx_debug_fetch.argtypes = [vp, i32, i32, vp, i64, C.POINTER(i64)]
+    lib.amx_debug_fetch.restype = i32
+    lib.amx_device_bytes.argtypes = [vp]
+    lib.amx_device_bytes.restype = i64
+    _lib = lib
+    return lib
+
+
+def check(lib: C.CDLL, handle, code: int) -> None:
+    """Maps C status codes onto the exception types the reference raises (ValueError for configuration / argument
+    problems, RuntimeError otherwise)."""
+    if code == AMX_OK:
+        return
+    message = lib.amx_last_error(handle)
+    message = message.decode() if message else f"liballophant_amx error {code}"
+    if code == AMX_EINVAL:
+        raise ValueError(message)
+    if code == AMX_ENOMEM:
+        raise MemoryError(message)
+    raise RuntimeError(message)

@@ -57,10 +57,10 @@ def tiny_encoder(layers: int = 2) -> Dict[str, Any]:
         "conv_dim": 32,
         "conv_kernel": [10, 3, 3, 3, 3, 2, 2],
         "conv_stride": [5, 2, 2, 2, 2, 2, 2],
-        "hidden": 64,
+        "hidden": 128,  # head_dim 64 like XLS-R (the attention kernel is specialised for it)
         "layers": layers,
-        "heads": 4,
-        "ffn": 128,
+        "heads": 2,
+        "ffn": 256,
         "pos_kernel": 16,
         "pos_groups": 4,
         "eps": 1e-5,

@@ -1,0 +1,155 @@
+/* liballophant_amx -- C ABI of the MI355X-native Allophant acoustic-encoder forward path.
+ *
+ * The reference (kgnlp/allophant) has no FFI for its network: the only native boundary upstream is the pyo3 module
+ * `allophant.phonemes` (src/lib.rs:9-18), which is not on this path.  The drop-in boundary is therefore the Python-level
+ * call `Estimator.predict(batch, target_feature_indices, log_probabilities)` (allophant/estimator.py:1035-1046) on a
+ * model restored by `Estimator.restore` (estimator.py:1085-1126).  Every entry point below names the reference interface
+ * it replaces; the reference-side binding (ctypes) is shown in INTEGRATION.md and implemented in
+ * allophant_amd/lib.py + allophant_amd/estimator.py.
+ *
+ * Conventions (following the reference's own FFI habits): every call returns 0 on success or a
+ * negative AMX_E* code, with a message retrievable through amx_last_error(); handles are not re-entrant (one handle per
+ * GPU / stream, like the single-threaded `torch.inference_mode` caller upstream); the library owns packed weights and
+ * workspace, the caller owns input and output buffers.  No torch types appear in any signature.
+ */
+#ifndef ALLOPHANT_AMX_H
+#define ALLOPHANT_AMX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMX_ABI_VERSION 1
+
+#define AMX_MAX_CONV 8
+#define AMX_MAX_DEPS 64
+#define AMX_NAME_LEN 48
+
+/* error codes */
+#define AMX_OK 0
+#define AMX_EINVAL (-1)   /* bad argument / unsupported configuration (the reference raises ValueError) */
+#define AMX_EHIP (-2)     /* HIP runtime failure */
+#define AMX_ESTATE (-3)   /* call order violated (e.g. composition model without an inventory) */
+#define AMX_ENOMEM (-4)
+
+/* arithmetic modes of the GEMM-shaped products (activations between kernels are 16-bit planes, residual stream,
+ * LayerNorm, softmax and all accumulation are fp32):
+ *   BF16 / F16      one 16-bit plane per operand
+ *   BF16X3 / F16X3  hi/lo split planes, 3 MFMAs per product: fp32-grade results (the 1e-3 logit parity gate) */
+#define AMX_PREC_BF16 0
+#define AMX_PREC_F16 1
+#define AMX_PREC_BF16X3 2
+#define AMX_PREC_F16X3 3
+
+/* amx_forward flags */
+#define AMX_FLAG_HOST_IO 1u      /* audio / out are host pointers; the library stages them over PCIe */
+#define AMX_FLAG_RAW_LOGITS 2u   /* `log_probabilities=False` of Estimator.predict (estimator.py:1037,1040-1046) */
+#define AMX_FLAG_KEEP_HIDDEN 4u  /* keep every encoder hidden state for amx_debug_fetch */
+
+/* dependency codes in amx_class_desc.deps */
+#define AMX_DEP_OUTPUT (-1)                 /* "OUTPUT"   (allophant/config.py:636) */
+#define AMX_DEP_OUTPUT_LAYER(i) (-2 - (i))  /* "OUTPUT_i" (allophant/config.py:637, acoustic_model.py:478-483) */
+
+typedef struct amx_handle_s* amx_handle;
+
+/* Shape of the wav2vec 2.0 encoder (`transformers.Wav2Vec2Config` read at acoustic_model.py:818-826) and of the
+ * projection (`ProjectionConfig`, allophant/config.py:679-712). */
+typedef struct amx_config {
+    int32_t abi_version;                 /* AMX_ABI_VERSION */
+    int32_t n_conv;                      /* feature-extractor conv layers (7) */
+    int32_t conv_dim;                    /* 512 */
+    int32_t conv_kernel[AMX_MAX_CONV];   /* 10,3,3,3,3,2,2 */
+    int32_t conv_stride[AMX_MAX_CONV];   /* 5,2,2,2,2,2,2 */
+    int32_t hidden;                      /* 1024 */
+    int32_t layers;                      /* 24 */
+    int32_t heads;                       /* 16 (head_dim must be 64) */
+    int32_t ffn;                         /* 4096 */
+    int32_t pos_kernel;                  /* 128 */
+    int32_t pos_groups;                  /* 16 */
+    float eps;                           /* layer_norm_eps 1e-5 */
+    int32_t do_normalize;                /* preprocessor do_normalize (acoustic_model.py:815,841-843) */
+    int32_t dependency_blanks;           /* ProjectionConfig.dependency_blanks */
+    int32_t embedding_size;              /* EmbeddingCompositionConfig.embedding_size, 0 = no composition layer */
+    int32_t allophone_layer;             /* 1: predict mode also publishes "phone" (acoustic_model.py:161-167) */
+    int32_t precision;                   /* AMX_PREC_* */
+} amx_config;
+
+/* One classifier of the hierarchical projection (`ProjectionEntryConfig` / `AttributeNode`,
+ * allophant/config.py:624-644, allophant/attribute_graph.py:17-41), in configuration order. */
+typedef struct amx_class_desc {
+    char name[AMX_NAME_LEN];
+    int32_t size;                   /* classes without the CTC blank */
+    int32_t out_features;           /* rows of `_time_distributed_layer.weight` (size+1, or embedding_size) */
+    int32_t n_deps;
+    int32_t deps[AMX_MAX_DEPS];     /* >= 0: index of another class; AMX_DEP_OUTPUT; AMX_DEP_OUTPUT_LAYER(i) */
+} amx_class_desc;
+
+/* One tensor of `Allophant.state_dict()` (= `Checkpoint.model_state`, estimator.py:216), host fp32, reference key
+ * names.  The library packs them itself: conv weights to tap-major, weight-norm folded into
+ * the positional conv, Q/K/V fused with the 1/sqrt(head_dim) scale, hi/lo 16-bit planes. */
+typedef struct amx_tensor {
+    const char* name;
+    const float* data;
+    int64_t numel;
+} amx_tensor;
+
+/* One entry of `Predictions.outputs` (acoustic_model.py:908-926): a [T, N, C] time-major fp32 block at `offset` floats
+ * into the output buffer.  "phone" and "phoneme" share one block, as they share one tensor upstream. */
+typedef struct amx_output_desc {
+    char name[AMX_NAME_LEN];
+    int32_t classes;   /* C (incl. blank) */
+    int64_t offset;
+} amx_output_desc;
+
+/* Replaces `Estimator.restore` + `Allophant.from_config` + `load_state_dict` (estimator.py:1085-1126,
+ * acoustic_model.py:988-1025): builds the device-resident model on `device`. */
+int amx_create(amx_handle* out, int device, const amx_config* config, const amx_class_desc* classes, int n_classes,
+               const amx_tensor* tensors, int n_tensors);
+int amx_destroy(amx_handle h);
+const char* amx_last_error(amx_handle h); /* h may be NULL for errors of amx_create */
+
+/* Replaces the `target_feature_indices` argument of `Estimator.predict` / `EmbeddingCompositionLayer.forward`
+ * (acoustic_model.py:219-234): `tfi` is the int64 [P, F] `composition_feature_matrix`
+ * (phonetic_features.py:808-818), `category_offsets` the int64 [F] buffer `_category_offsets`
+ * (acoustic_model.py:196-207, 214-217).  Host pointers.  Stays in effect until replaced. */
+int amx_set_inventory(amx_handle h, const int64_t* tfi, int phones, int features, const int64_t* category_offsets);
+
+/* Output geometry for a batch of N utterances padded to L samples: T = frames of the padded length,
+ * `total` = floats the caller must provide to amx_forward.  `descs` may be NULL to query `n_outputs` only. */
+int amx_output_layout(amx_handle h, int N, int64_t L, amx_output_desc* descs, int* n_outputs, int64_t* T,
+                      int64_t* total);
+
+/* Replaces `Estimator.predict(batch, tfi, log_probabilities)` (estimator.py:1035-1046):
+ *   audio        fp32 [N, L], zero right-padded to L == max(lengths) (batching.py:174, utils.py:62-63); device pointer
+ *                unless AMX_FLAG_HOST_IO
+ *   lengths      int64 [N] valid samples per utterance, HOST pointer
+ *   out          fp32 `total` floats laid out per amx_output_layout; device pointer unless AMX_FLAG_HOST_IO
+ *   out_lengths  int64 [N] frames per utterance (`Predictions.lengths`), HOST pointer
+ *   stream       hipStream_t (NULL = default stream).  Work is enqueued asynchronously; call amx_synchronize or
+ *                synchronize the stream before reading `out` (with AMX_FLAG_HOST_IO the call returns synchronised). */
+int amx_forward(amx_handle h, const float* audio, const int64_t* lengths, int N, int64_t L, float* out,
+                int64_t* out_lengths, uint32_t flags, void* stream);
+int amx_synchronize(amx_handle h, void* stream);
+
+/* Replaces `GreedyCTCDecoder.__call__` (predictions.py:194-207) for every output of the last amx_forward (device
+ * `out` buffer of that call): tokens/timesteps are int64 [n_outputs, N, T] (first counts[o,n] entries valid, timesteps
+ * 1-based), counts int32 [n_outputs, N], scores fp32 [n_outputs, N].  All DEVICE pointers. */
+int amx_greedy_ctc(amx_handle h, const float* out, int N, int64_t L, int64_t* tokens, int64_t* timesteps,
+                   int32_t* counts, float* scores, void* stream);
+
+/* Test hook: copies an intermediate of the last amx_forward to host fp32.
+ *   what = 0: conv feature extractor output [N, T, conv_dim] (after the last GELU)
+ *   what = 1: hidden_states[index] [N, T, hidden]  (needs AMX_FLAG_KEEP_HIDDEN; index == layers is the final LayerNorm)
+ *   what = 2: raw logits buffer [N*T, ld] (index ignored); returns ld through *ld_out */
+int amx_debug_fetch(amx_handle h, int what, int index, float* host_out, int64_t capacity, int64_t* ld_out);
+
+/* number of bytes of device memory held by the handle (weights + workspace) */
+int64_t amx_device_bytes(amx_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALLOPHANT_AMX_H */

@@ -44,7 +44,7 @@ def _load_into_reference(model, state):
     model.load_state_dict(full)
 
 
-def run_case(name, spec, n, length, ragged, inventory_phones, seed, store_weights, subsample=None, train_phones=None):
+def run_case(name, spec, n, length, ragged, inventory_phones, seed, store_weights, subsample=None, store_audio=True):
     S.validate(spec)
     torch.manual_seed(0)
     composed = bool(spec.get("embedding_size"))
@@ -109,7 +109,7 @@ def run_case(name, spec, n, length, ragged, inventory_phones, seed, store_weight
     data = {
         "spec_json": np.frombuffer(json.dumps(spec).encode(), dtype=np.uint8),
         "seed": np.int64(seed),
-        "audio": _np(audio) if store_weights else np.zeros(0, np.float32),
+        "audio": _np(audio) if store_audio else np.zeros(0, np.float32),
         "audio_args": np.array([n, length, 1234 + seed, int(ragged)], dtype=np.int64),
         "lengths": _np(lengths),
         "frame_lengths": _np(pred.lengths),
@@ -240,23 +240,23 @@ def main():
         ]
         spec["dependency_blanks"] = False
         run_case("g2_tiny_hierarchical", spec, n=2, length=5000, ragged=True, inventory_phones=6, seed=2,
-                 store_weights=True)
+                 store_weights=False)
     if "g2b" in which:
         enc = S.tiny_encoder(2)
         spec = S.hierarchical_spec(enc, ["syllabic", "long", "nasal"], embedding_size=16, train_phonemes=9, n_features=5,
                                    dependency_blanks=True)
         run_case("g2b_tiny_hierarchical_blanks", spec, n=2, length=4000, ragged=True, inventory_phones=12, seed=3,
-                 store_weights=True)
+                 store_weights=False)
     if "g5" in which:
         # baseline schema: single non-composed phoneme head (BASELINE config 1 plumbing), tiny shape
         spec = S.baseline_spec(S.tiny_encoder(2), phonemes=10)
-        run_case("g5_tiny_baseline", spec, n=1, length=4800, ragged=False, inventory_phones=0, seed=5, store_weights=True)
+        run_case("g5_tiny_baseline", spec, n=1, length=4800, ragged=False, inventory_phones=0, seed=5, store_weights=False)
     if "g3" in which:
         # G3: full XLS-R shape, procedural weights (seed 0), 2 x 3 s ragged; sub-sampled tensors only
         spec = S.multitask_spec(S.xlsr_300m_encoder(), allophone_layer=True)
         spec["shared_phones"] = 80
         run_case("g3_xlsr_multitask", spec, n=2, length=48000, ragged=True, inventory_phones=27, seed=0,
-                 store_weights=False, subsample=[0, 1, 12, 24])
+                 store_weights=False, subsample=[0, 1, 12, 24], store_audio=False)
 
 
 if __name__ == "__main__":
