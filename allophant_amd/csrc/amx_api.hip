@@ -92,6 +92,12 @@ struct amx_handle_s {
     int64_t* h_lengths_pinned = nullptr;
     int* h_frames_pinned = nullptr;
     int pinned_cap = 0;
+    // per-kernel-class HIP event timing (AMX_FLAG_TIMING)
+    struct Span { int cls; hipEvent_t a, b; };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> event_pool;
+    bool timing = false;
+    hipStream_t timing_stream = nullptr;
     // last forward geometry
     int last_N = 0;
     int64_t last_L = 0, last_T = 0;
@@ -145,6 +151,26 @@ int ws_get(amx_handle h, const char* name, size_t bytes, void** out, bool zero_o
 }
 
 int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// brackets one kernel launch with HIP events on the launch stream when timing is enabled
+struct Timed {
+    amx_handle h;
+    hipEvent_t b = nullptr;
+    Timed(amx_handle h_, int cls) : h(h_) {
+        if (!h->timing) return;
+        hipEvent_t a = nullptr;
+        auto get = [&](hipEvent_t& e) {
+            if (!h->event_pool.empty()) { e = h->event_pool.back(); h->event_pool.pop_back(); }
+            else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+        };
+        get(a); get(b);
+        if (!a || !b) { b = nullptr; return; }
+        (void)hipEventRecord(a, h->timing_stream);
+        h->spans.push_back({cls, a, b});
+    }
+    ~Timed() { if (b) (void)hipEventRecord(b, h->timing_stream); }
+};
+inline int gemm_class(const GemmParams& g) { return g.N <= 64 ? AMX_KC_GEMM_128x64 : AMX_KC_GEMM_128x128; }
 
 struct TensorMap {
     std::map<std::string, const amx_tensor*> m;
@@ -491,6 +517,8 @@ extern "C" int amx_destroy(amx_handle h) {
         if (kv.second.p) hipFree(kv.second.p);
     if (h->h_lengths_pinned) hipHostFree(h->h_lengths_pinned);
     if (h->h_frames_pinned) hipHostFree(h->h_frames_pinned);
+    for (auto& sp : h->spans) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
+    for (auto e : h->event_pool) hipEventDestroy(e);
     delete h;
     return AMX_OK;
 }
@@ -632,6 +660,8 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     const int NT = h->NT, prec = h->prec;
     const int C = c.conv_dim, D = c.hidden, F = c.ffn, H = c.heads;
     const bool keep = (flags & AMX_FLAG_KEEP_HIDDEN) != 0;
+    h->timing = (flags & AMX_FLAG_TIMING) != 0;
+    h->timing_stream = s;
 
     int64_t Ts[AMX_MAX_CONV + 1];
     Ts[0] = L;
@@ -728,10 +758,10 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     HIPCHK(h, hipMemcpyAsync(d_frames, h->h_frames_pinned, (size_t)N * 4, hipMemcpyHostToDevice, s));
 
     // ---- input normalisation statistics + conv layer 0 (fused norm + conv + LN + GELU) ----
-    launch_audio_stats(d_audio, (const int64_t*)d_len, N, L, (double*)d_partial, (float*)d_stats, c.do_normalize, s);
-    launch_conv0(prec, d_audio, (const int64_t*)d_len, (const float*)d_stats, N, L, (int)Ts[1], C, c.conv_kernel[0],
+    { Timed t_(h, AMX_KC_OTHER); launch_audio_stats(d_audio, (const int64_t*)d_len, N, L, (double*)d_partial, (float*)d_stats, c.do_normalize, s); }
+    { Timed t_(h, AMX_KC_CONV0); launch_conv0(prec, d_audio, (const int64_t*)d_len, (const float*)d_stats, N, L, (int)Ts[1], C, c.conv_kernel[0],
                  c.conv_stride[0], h->c0_w, h->conv_b[0], h->conv_g[0], h->conv_be[0], 1e-5f, c.do_normalize, actA,
-                 rows1 * C, s);
+                 rows1 * C, s); }
     // ---- conv layers 1..n-1: implicit GEMM over overlapping channels-last windows, then LN + GELU rows ----
     void* cur = actA;
     int64_t cur_plane = rows1 * C;
@@ -745,21 +775,21 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         g.M = (int)rows_out; g.N = C; g.K = C * c.conv_kernel[i];
         g.scale = 1.f; g.bias = h->conv_b[i];
         g.out_f32 = (float*)preln; g.ldo = C;
-        launch_gemm(prec, g, s);
+        { Timed t_(h, gemm_class(g)); launch_gemm(prec, g, s); }
         const bool last = i == c.n_conv - 1;
         const int64_t out_plane = rows_out * C;
         if (!last) {
-            launch_rownorm(prec, (const float*)preln, C, rows_out, C, h->conv_g[i], h->conv_be[i], 1, nullptr, nullptr, 1e-5f,
-                           0.f, other, out_plane, C, nullptr, 0, s);
+            { Timed t_(h, AMX_KC_ROWNORM); launch_rownorm(prec, (const float*)preln, C, rows_out, C, h->conv_g[i], h->conv_be[i], 1, nullptr, nullptr, 1e-5f,
+                           0.f, other, out_plane, C, nullptr, 0, s); }
         } else if (!keep) {
             // last conv layer: LN + GELU, then the feature-projection LayerNorm in the same pass
-            launch_rownorm(prec, (const float*)preln, C, rows_out, C, h->conv_g[i], h->conv_be[i], 1, h->fp_g, h->fp_b, 1e-5f,
-                           c.eps, other, out_plane, C, nullptr, 0, s);
+            { Timed t_(h, AMX_KC_ROWNORM); launch_rownorm(prec, (const float*)preln, C, rows_out, C, h->conv_g[i], h->conv_be[i], 1, h->fp_g, h->fp_b, 1e-5f,
+                           c.eps, other, out_plane, C, nullptr, 0, s); }
         } else {
-            launch_rownorm(prec, (const float*)preln, C, rows_out, C, h->conv_g[i], h->conv_be[i], 1, nullptr, nullptr, 1e-5f,
-                           0.f, nullptr, 0, 0, conv_dbg, C, s);
-            launch_rownorm(prec, conv_dbg, C, rows_out, C, h->fp_g, h->fp_b, 0, nullptr, nullptr, c.eps, 0.f, other, out_plane,
-                           C, nullptr, 0, s);
+            { Timed t_(h, AMX_KC_ROWNORM); launch_rownorm(prec, (const float*)preln, C, rows_out, C, h->conv_g[i], h->conv_be[i], 1, nullptr, nullptr, 1e-5f,
+                           0.f, nullptr, 0, 0, conv_dbg, C, s); }
+            { Timed t_(h, AMX_KC_ROWNORM); launch_rownorm(prec, conv_dbg, C, rows_out, C, h->fp_g, h->fp_b, 0, nullptr, nullptr, c.eps, 0.f, other, out_plane,
+                           C, nullptr, 0, s); }
         }
         std::swap(cur, other);
         cur_plane = out_plane;
@@ -773,12 +803,12 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         g.scale = 1.f; g.bias = h->fp_bias;
         g.row_len = (const int*)d_frames; g.rows_T = T;
         g.out_f32 = (float*)hbuf; g.ldo = D;
-        launch_gemm(prec, g, s);
+        { Timed t_(h, gemm_class(g)); launch_gemm(prec, g, s); }
     }
     // ---- positional conv embedding: h += GELU(grouped conv(h)) ----
     {
-        launch_posconv_pack(prec, (const float*)hbuf, N, T, D, c.pos_groups, c.pos_kernel / 2, Tpad, hg,
-                            (int64_t)N * Tpad * D, s);
+        { Timed t_(h, AMX_KC_OTHER); launch_posconv_pack(prec, (const float*)hbuf, N, T, D, c.pos_groups, c.pos_kernel / 2, Tpad, hg,
+                            (int64_t)N * Tpad * D, s); }
         GemmParams g{};
         g.A = hg; g.a_plane = (int64_t)N * Tpad * D; g.lda = cg; g.rows_per_batch = T; g.a_batch_stride = (int64_t)Tpad * cg;
         g.za = (int64_t)N * Tpad * cg;
@@ -787,15 +817,15 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         g.M = (int)M; g.N = cg; g.K = cg * c.pos_kernel;
         g.scale = 1.f; g.bias = h->pos_b; g.zbias = cg; g.act = 1;
         g.residual = (const float*)hbuf; g.ldr = D; g.out_f32 = (float*)hbuf; g.ldo = D; g.zout = cg;
-        launch_gemm_grouped(prec, g, c.pos_groups, s);
+        { Timed t_(h, AMX_KC_GEMM_128x64); launch_gemm_grouped(prec, g, c.pos_groups, s); }
     }
     // ---- transformer encoder (pre-LN) ----
     const int64_t xp_plane = M * D;
     for (int l = 0; l < c.layers; ++l) {
         const Layer& ly = h->layers[l];
         if (saved[l]) HIPCHK(h, hipMemcpyAsync(saved[l], hbuf, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s));
-        launch_rownorm(prec, (const float*)hbuf, D, M, D, ly.ln1_g, ly.ln1_b, 0, nullptr, nullptr, c.eps, 0.f, xp, xp_plane, D,
-                       nullptr, 0, s);
+        { Timed t_(h, AMX_KC_ROWNORM); launch_rownorm(prec, (const float*)hbuf, D, M, D, ly.ln1_g, ly.ln1_b, 0, nullptr, nullptr, c.eps, 0.f, xp, xp_plane, D,
+                       nullptr, 0, s); }
         {
             GemmParams g{};
             g.A = xp; g.a_plane = xp_plane; g.lda = D; g.rows_per_batch = M;
@@ -805,7 +835,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             g.mode = 1; g.q = qb; g.k = kb; g.vt = vtb;
             g.qk_plane = (int64_t)N * H * Tp * 64; g.vt_plane = (int64_t)N * H * Tp * 64;
             g.T = T; g.Tp = Tp; g.H = H; g.dh = 64;
-            launch_gemm(prec, g, s);
+            { Timed t_(h, gemm_class(g)); launch_gemm(prec, g, s); }
         }
         {
             AttnParams a{};
@@ -814,7 +844,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             a.out = ao; a.out_plane = xp_plane;
             a.frame_len = (const int*)d_frames;
             a.N = N; a.H = H; a.T = T; a.Tp = Tp; a.dh = 64;
-            launch_attention(prec, a, s);
+            { Timed t_(h, AMX_KC_ATTENTION); launch_attention(prec, a, s); }
         }
         {
             GemmParams g{};
@@ -823,10 +853,10 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             g.M = (int)M; g.N = D; g.K = D;
             g.scale = 1.f; g.bias = ly.bo;
             g.residual = (const float*)hbuf; g.ldr = D; g.out_f32 = (float*)hbuf; g.ldo = D;
-            launch_gemm(prec, g, s);
+            { Timed t_(h, gemm_class(g)); launch_gemm(prec, g, s); }
         }
-        launch_rownorm(prec, (const float*)hbuf, D, M, D, ly.ln2_g, ly.ln2_b, 0, nullptr, nullptr, c.eps, 0.f, xp, xp_plane, D,
-                       nullptr, 0, s);
+        { Timed t_(h, AMX_KC_ROWNORM); launch_rownorm(prec, (const float*)hbuf, D, M, D, ly.ln2_g, ly.ln2_b, 0, nullptr, nullptr, c.eps, 0.f, xp, xp_plane, D,
+                       nullptr, 0, s); }
         {
             GemmParams g{};
             g.A = xp; g.a_plane = xp_plane; g.lda = D; g.rows_per_batch = M;
@@ -834,7 +864,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             g.M = (int)M; g.N = F; g.K = D;
             g.scale = 1.f; g.bias = ly.b1; g.act = 1;
             g.out_p = ff; g.out_plane = M * F; g.ldp = F;
-            launch_gemm(prec, g, s);
+            { Timed t_(h, gemm_class(g)); launch_gemm(prec, g, s); }
         }
         {
             GemmParams g{};
@@ -843,11 +873,11 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             g.M = (int)M; g.N = D; g.K = F;
             g.scale = 1.f; g.bias = ly.b2;
             g.residual = (const float*)hbuf; g.ldr = D; g.out_f32 = (float*)hbuf; g.ldo = D;
-            launch_gemm(prec, g, s);
+            { Timed t_(h, gemm_class(g)); launch_gemm(prec, g, s); }
         }
     }
-    launch_rownorm(prec, (const float*)hbuf, D, M, D, h->fln_g, h->fln_b, 0, nullptr, nullptr, c.eps, 0.f, xp, xp_plane, D,
-                   (float*)hfin, D, s);
+    { Timed t_(h, AMX_KC_ROWNORM); launch_rownorm(prec, (const float*)hbuf, D, M, D, h->fln_g, h->fln_b, 0, nullptr, nullptr, c.eps, 0.f, xp, xp_plane, D,
+                   (float*)hfin, D, s); }
 
     // ---- hierarchical projection ----
     const int E = c.embedding_size;
@@ -876,8 +906,8 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             }
             HIPCHK(h, hipMemcpyAsync(st.parts_dev, st.parts.data(), st.parts.size() * sizeof(ConcatPart), hipMemcpyHostToDevice, s));
             HIPCHK(h, hipStreamSynchronize(s));  // st.parts is pageable host memory
-            launch_concat(prec, st.parts_dev, (int)st.parts.size(), (const float*)logits, h->ld_logits, M, cat, M * st.Kpad,
-                          st.Kpad, st.Kpad, s);
+            { Timed t_(h, AMX_KC_OTHER); launch_concat(prec, st.parts_dev, (int)st.parts.size(), (const float*)logits, h->ld_logits, M, cat, M * st.Kpad,
+                          st.Kpad, st.Kpad, s); }
             A = cat; a_plane = M * st.Kpad; lda = st.Kpad;
         }
         GemmParams g{};
@@ -887,7 +917,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         g.scale = 1.f; g.bias = st.bias;
         if (st.composed) {
             g.out_p = ebuf; g.out_plane = M * E; g.ldp = E;
-            launch_gemm(prec, g, s);
+            { Timed t_(h, gemm_class(g)); launch_gemm(prec, g, s); }
             // logits = (e @ composed) / sqrt(E)   (acoustic_model.py:234)
             GemmParams g2{};
             g2.A = ebuf; g2.a_plane = M * E; g2.lda = E; g2.rows_per_batch = M;
@@ -895,14 +925,14 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             g2.M = (int)M; g2.N = h->P1; g2.K = E;
             g2.scale = 1.0f / sqrtf((float)E);
             g2.out_f32 = (float*)logits + h->col[st.classes[0]]; g2.ldo = h->ld_logits;
-            launch_gemm(prec, g2, s);
+            { Timed t_(h, gemm_class(g2)); launch_gemm(prec, g2, s); }
         } else {
             g.out_f32 = (float*)logits + h->col[st.classes[0]]; g.ldo = h->ld_logits;
-            launch_gemm(prec, g, s);
+            { Timed t_(h, gemm_class(g)); launch_gemm(prec, g, s); }
         }
     }
-    launch_logsoftmax_out(h->out_unique_dev, (int)h->out_unique.size(), (const float*)logits, h->ld_logits, N, T,
-                          (flags & AMX_FLAG_RAW_LOGITS) ? 0 : 1, d_out, s);
+    { Timed t_(h, AMX_KC_OTHER); launch_logsoftmax_out(h->out_unique_dev, (int)h->out_unique.size(), (const float*)logits, h->ld_logits, N, T,
+                          (flags & AMX_FLAG_RAW_LOGITS) ? 0 : 1, d_out, s); }
     HIPCHK(h, hipGetLastError());
     if (flags & AMX_FLAG_HOST_IO) {
         HIPCHK(h, hipMemcpyAsync(out, d_out, (size_t)total * 4, hipMemcpyDeviceToHost, s));
@@ -921,16 +951,43 @@ extern "C" int amx_synchronize(amx_handle h, void* stream) {
     return AMX_OK;
 }
 
-extern "C" int amx_greedy_ctc(amx_handle h, const float* out, int N, int64_t L, int64_t* tokens, int64_t* timesteps,
-                              int32_t* counts, float* scores, void* stream) {
-    if (!h || !out || !tokens || !timesteps || !counts || !scores) return AMX_EINVAL;
+extern "C" int amx_greedy_ctc(amx_handle h, const float* out, const int64_t* frame_lengths, int N, int64_t L,
+                              int64_t* tokens, int64_t* timesteps, int32_t* counts, float* scores, void* stream) {
+    if (!h || !out || !frame_lengths || !tokens || !timesteps || !counts || !scores) return AMX_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
-    if (h->last_N != N || h->last_L != L || h->layout_N != N) return fail(h, AMX_ESTATE, "amx_greedy_ctc must follow amx_forward with the same batch geometry");
-    const int T = (int)h->last_T;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = compute_layout(h, N, L);  // output block geometry is a function of (N, L, inventory) only
+    if (rc) return rc;
+    const int T = (int)h->layout_T;
     if ((size_t)T * 4 + 2048 > 64 * 1024) return fail(h, AMX_EINVAL, "utterance too long for the on-device greedy decoder");
-    launch_greedy_ctc(h->out_all_dev, (int)h->out_all.size(), out, (const int*)h->ws["frames"].p, N, T, tokens, timesteps,
-                      counts, scores, (hipStream_t)stream);
+    std::vector<int> fl(N);
+    for (int n = 0; n < N; ++n) {
+        if (frame_lengths[n] < 0 || frame_lengths[n] > T) return fail(h, AMX_EINVAL, "frame length out of range");
+        fl[n] = (int)frame_lengths[n];
+    }
+    void* d_fl;
+    if ((rc = ws_get(h, "ctc_frames", (size_t)N * 4, &d_fl))) return rc;
+    HIPCHK(h, hipMemcpyAsync(d_fl, fl.data(), (size_t)N * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipStreamSynchronize(s));  // fl is pageable host memory
+    launch_greedy_ctc(h->out_all_dev, (int)h->out_all.size(), out, (const int*)d_fl, N, T, tokens, timesteps, counts, scores, s);
     HIPCHK(h, hipGetLastError());
+    return AMX_OK;
+}
+
+extern "C" int amx_timing_fetch(amx_handle h, float* ms, int32_t* launches, int n_classes) {
+    if (!h || !ms || !launches || n_classes < AMX_KC_COUNT) return AMX_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->timing_stream));
+    for (int i = 0; i < n_classes; ++i) { ms[i] = 0.f; launches[i] = 0; }
+    for (auto& sp : h->spans) {
+        float t = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&t, sp.a, sp.b));
+        ms[sp.cls] += t;
+        launches[sp.cls] += 1;
+        h->event_pool.push_back(sp.a);
+        h->event_pool.push_back(sp.b);
+    }
+    h->spans.clear();
     return AMX_OK;
 }
 

@@ -213,7 +213,7 @@ class Estimator:
         self._inventory = tfi_cpu
 
     def predict(self, batch: Batch, target_feature_indices: Optional[Tensor] = None, log_probabilities: bool = True,
-                _keep_hidden: bool = False) -> Predictions:
+                _keep_hidden: bool = False, _timing: bool = False) -> Predictions:
         """``Estimator.predict`` (reference estimator.py:1035-1046)."""
         if self._spec.get("embedding_size"):
             if target_feature_indices is None:
@@ -245,6 +245,8 @@ class Estimator:
             flags = 0 if log_probabilities else _lib.FLAG_RAW_LOGITS
             if _keep_hidden:
                 flags |= _lib.FLAG_KEEP_HIDDEN
+            if _timing:
+                flags |= _lib.FLAG_TIMING
             stream = torch.cuda.current_stream(self._device).cuda_stream
             code = self._lib.amx_forward(
                 self._handle, C.c_void_p(audio.data_ptr()), C.cast(lengths.data_ptr(), C.POINTER(C.c_int64)), N, L,
@@ -275,8 +277,10 @@ class Estimator:
             counts = torch.empty(len(names), N, dtype=torch.int32, device=self._device)
             scores = torch.empty(len(names), N, dtype=torch.float32, device=self._device)
             stream = torch.cuda.current_stream(self._device).cuda_stream
+            frame_lengths = predictions.lengths.detach().to("cpu", torch.int64).contiguous()
             code = self._lib.amx_greedy_ctc(
-                self._handle, C.c_void_p(predictions._flat.data_ptr()), N, L, C.c_void_p(tokens.data_ptr()),
+                self._handle, C.c_void_p(predictions._flat.data_ptr()),
+                C.cast(frame_lengths.data_ptr(), C.POINTER(C.c_int64)), N, L, C.c_void_p(tokens.data_ptr()),
                 C.c_void_p(timesteps.data_ptr()), C.c_void_p(counts.data_ptr()), C.c_void_p(scores.data_ptr()),
                 C.c_void_p(stream))
             _lib.check(self._lib, self._handle, code)
@@ -318,6 +322,15 @@ class Estimator:
         if not hasattr(self, "_geom"):
             raise RuntimeError("no forward pass yet")
         return self._geom
+
+    def timing_fetch(self) -> Dict[str, Tuple[float, int]]:
+        """Measurement hook: {kernel class: (total ms, launches)} of the ``predict(..., _timing=True)`` calls since the
+        previous fetch, from HIP events recorded on the launch stream."""
+        n = len(_lib.KERNEL_CLASSES)
+        ms = (C.c_float * n)()
+        launches = (C.c_int32 * n)()
+        _lib.check(self._lib, self._handle, self._lib.amx_timing_fetch(self._handle, ms, launches, n))
+        return {k: (float(ms[i]), int(launches[i])) for i, k in enumerate(_lib.KERNEL_CLASSES)}
 
     def synchronize(self) -> None:
         stream = torch.cuda.current_stream(self._device).cuda_stream

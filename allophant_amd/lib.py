@@ -16,7 +16,8 @@ AMX_NAME_LEN = 48
 
 AMX_OK, AMX_EINVAL, AMX_EHIP, AMX_ESTATE, AMX_ENOMEM = 0, -1, -2, -3, -4
 PRECISIONS = {"bf16": 0, "f16": 1, "bf16x3": 2, "f16x3": 3}
-FLAG_HOST_IO, FLAG_RAW_LOGITS, FLAG_KEEP_HIDDEN = 1, 2, 4
+FLAG_HOST_IO, FLAG_RAW_LOGITS, FLAG_KEEP_HIDDEN, FLAG_TIMING = 1, 2, 4, 8
+KERNEL_CLASSES = ["gemm_128x128", "gemm_128x64", "attention", "rownorm", "conv0", "other"]
 DEP_OUTPUT = -1
 
 LIB_NAME = "liballophant_amx.so"
@@ -25,7 +26,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 # every symbol include/allophant_amx.h declares
 EXPORTS = [
     "amx_create", "amx_destroy", "amx_last_error", "amx_set_inventory", "amx_output_layout", "amx_forward",
-    "amx_synchronize", "amx_greedy_ctc", "amx_debug_fetch", "amx_device_bytes",
+    "amx_synchronize", "amx_greedy_ctc", "amx_debug_fetch", "amx_device_bytes", "amx_timing_fetch",
 ]
 
 
@@ -90,10 +91,12 @@ def load() -> C.CDLL:
     lib.amx_forward.restype = i32
     lib.amx_synchronize.argtypes = [vp, vp]
     lib.amx_synchronize.restype = i32
-    lib.amx_greedy_ctc.argtypes = [vp, vp, i32, i64, vp, vp, vp, vp, vp]
+    lib.amx_greedy_ctc.argtypes = [vp, vp, C.POINTER(i64), i32, i64, vp, vp, vp, vp, vp]
     lib.amx_greedy_ctc.restype = i32
     lib.amx_debug_fetch.argtypes = [vp, i32, i32, vp, i64, C.POINTER(i64)]
     lib.amx_debug_fetch.restype = i32
+    lib.amx_timing_fetch.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int32), i32]
+    lib.amx_timing_fetch.restype = i32
     lib.amx_device_bytes.argtypes = [vp]
     lib.amx_device_bytes.restype = i64
     _lib = lib

@@ -1,0 +1,114 @@
+"""Utterance-level data parallelism over the GPUs of one node (one process per GPU, ``torch.distributed``; backend
+``"nccl"`` is RCCL over xGMI on ROCm, ``"gloo"`` on CPU for the tests).
+
+The prediction path is embarrassingly parallel over utterances: no operator mixes batch rows, so
+a batch is cut into contiguous blocks of utterances, every rank runs the full forward pass on its block with a full
+weight replica, and the only exchange is one gather of per-frame log-probabilities (plus the frame lengths) to rank 0,
+where the reference's decode loop consumes ``Predictions.outputs`` (run.py:765-774).  The reference itself is
+single-device (no DDP / NCCL anywhere upstream) -- this module is new functionality with no upstream counterpart.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+from .estimator import Batch, Predictions
+
+
+def shard_bounds(n: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous, balanced utterance blocks: the first ``n % world`` ranks get one utterance more."""
+    base, extra = divmod(n, world)
+    bounds = []
+    start = 0
+    for r in range(world):
+        size = base + (1 if r < extra else 0)
+        bounds.append((start, start + size))
+        start += size
+    return bounds
+
+
+def shard_batch(batch: Batch, rank: int, world: int) -> Optional[Batch]:
+    """Block ``rank`` of ``batch``, re-padded to its own longest utterance (the reference requires
+    ``L == max(lengths)``, utils.py:62-63).  Returns ``None`` for an empty block."""
+    lo, hi = shard_bounds(len(batch), world)[rank]
+    if hi <= lo:
+        return None
+    lengths = batch.lengths[lo:hi]
+    local_max = int(lengths.max())
+    return Batch(batch.audio_features[lo:hi, :local_max].contiguous(), lengths, batch.language_ids[lo:hi])
+
+
+def gather_predictions(local: Optional[Predictions], names_and_classes: List[Tuple[str, int]], total_utterances: int,
+                       device: torch.device, dst: int = 0, group=None,
+                       aliases: Optional[Dict[str, str]] = None) -> Optional[Predictions]:
+    """Gathers per-rank ``Predictions`` to ``dst``: one ``gather`` of a packed ``[T_max, n_max, sum(C)]`` fp32 block per
+    rank and one of the int64 frame lengths.  Returns the assembled ``Predictions`` ([T_max, N, C] per output, frames
+    beyond an utterance's length are zero) on ``dst`` and ``None`` elsewhere."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    bounds = shard_bounds(total_utterances, world)
+    n_max = max(hi - lo for lo, hi in bounds)
+    widths = [c for _, c in names_and_classes]
+    total_c = sum(widths)
+
+    # agree on the padded frame count (ranks may have different local max lengths)
+    t_local = 0 if local is None else next(iter(local.outputs.values())).shape[0]
+    t_tensor = torch.tensor([t_local], dtype=torch.int64, device=device)
+    dist.all_reduce(t_tensor, op=dist.ReduceOp.MAX, group=group)
+    t_max = int(t_tensor.item())
+
+    packed = torch.zeros(t_max, n_max, total_c, dtype=torch.float32, device=device)
+    lengths = torch.zeros(n_max, dtype=torch.int64, device=device)
+    if local is not None:
+        n_local = len(local.lengths)
+        col = 0
+        for (name, c) in names_and_classes:
+            out = local.outputs[name]
+            packed[: out.shape[0], :n_local, col: col + c] = out
+            col += c
+        lengths[:n_local] = local.lengths.to(device)
+    gathered_p = [torch.empty_like(packed) for _ in range(world)] if rank == dst else None
+    gathered_l = [torch.empty_like(lengths) for _ in range(world)] if rank == dst else None
+    dist.gather(packed, gathered_p, dst=dst, group=group)
+    dist.gather(lengths, gathered_l, dst=dst, group=group)
+    if rank != dst:
+        return None
+    outputs: Dict[str, Tensor] = {}
+    all_lengths = torch.cat([gathered_l[r][: hi - lo] for r, (lo, hi) in enumerate(bounds)])
+    col = 0
+    for (name, c) in names_and_classes:
+        parts = [gathered_p[r][:, : hi - lo, col: col + c] for r, (lo, hi) in enumerate(bounds) if hi > lo]
+        outputs[name] = torch.cat(parts, dim=1)
+        col += c
+    if aliases:
+        # e.g. {"phone": "phoneme"}: the allophone pass-through publishes one tensor under two names upstream
+        ordered: Dict[str, Tensor] = {}
+        for name, tensor in outputs.items():
+            for alias, target in aliases.items():
+                if target == name:
+                    ordered[alias] = tensor
+            ordered[name] = tensor
+        outputs = ordered
+    return Predictions(outputs, all_lengths.cpu())
+
+
+def unique_outputs(predictions: Predictions) -> Tuple[List[Tuple[str, int]], Dict[str, str]]:
+    """Splits ``predictions.outputs`` into the distinct tensors (name, classes) and the aliases that share storage with
+    one of them (``"phone"`` -> ``"phoneme"`` for allophone models, acoustic_model.py:161-167)."""
+    seen: Dict[int, str] = {}
+    unique: List[Tuple[str, int]] = []
+    aliases: Dict[str, str] = {}
+    items = list(predictions.outputs.items())
+    # the later name wins as the canonical one so that the alias precedes it like upstream ("phone" before "phoneme")
+    for name, tensor in reversed(items):
+        key = tensor.data_ptr()
+        if key in seen:
+            aliases[name] = seen[key]
+        else:
+            seen[key] = name
+            unique.append((name, tensor.shape[-1]))
+    unique.reverse()
+    return unique, aliases

@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""Benchmark of the Allophant acoustic-encoder forward path (``Estimator.predict``) on MI355X.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): encoder output frames/s over the whole node.  A *step* is one ``predict`` call over one batch of
+synthetic 16 kHz audio already resident in HBM: input normalisation, the 7-layer conv feature extractor, the 24-layer
+transformer encoder, all 36 attribute heads + the composed phoneme head, per-head log-softmax, and (N > 1) the RCCL gather
+of the log-probabilities to rank 0.  Workload at every N: BASELINE config 2 per GPU (multitask checkpoint schema,
+32 x 10 s utterances, 27-phone synthetic inventory standing in for 'es'), i.e. weak scaling: utterances are sharded
+across ranks with no data-path collective other than the final gather.  Weights are procedural (seed 0): real checkpoints
+are not reachable offline.
+
+Rank 0 prints ONE JSON line (see DESIGN.md section "Measurement" for the definition of every field).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from allophant_amd import spec as S, synthetic  # noqa: E402
+
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/f16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+HBM_PEAK_GBS = 8000.0
+
+
+def build_spec():
+    spec = S.multitask_spec(S.xlsr_300m_encoder(), allophone_layer=True)
+    spec["shared_phones"] = 80
+    return spec
+
+
+def gemm_flops(spec, n, length):
+    """Algorithmic FLOPs per step of the launches of each GEMM kernel instance (SURVEY.md Appendix D formulas)."""
+    C, D, F = spec["conv_dim"], spec["hidden"], spec["ffn"]
+    ts = [length]
+    for k, s in zip(spec["conv_kernel"], spec["conv_stride"]):
+        ts.append((ts[-1] - k) // s + 1)
+    T = ts[-1]
+    M = n * T
+    wide = 0
+    launches_wide = 0
+    for i in range(1, len(spec["conv_kernel"])):
+        wide += 2 * n * ts[i + 1] * C * C * spec["conv_kernel"][i]
+        launches_wide += 1
+    wide += 2 * M * C * D
+    launches_wide += 1
+    wide += spec["layers"] * 2 * M * (3 * D * D + D * D + 2 * D * F)
+    launches_wide += 4 * spec["layers"]
+    attr_cols = sum(c["size"] + 1 for c in spec["classes"] if c["name"] != "phoneme")
+    wide += 2 * M * D * attr_cols + 2 * M * D * spec["embedding_size"]
+    launches_wide += 2
+    narrow = 2 * M * D * (D // spec["pos_groups"]) * spec["pos_kernel"]
+    attention = spec["layers"] * 4 * M * T * D
+    total = wide + narrow + attention + 2 * n * ts[1] * C * spec["conv_kernel"][0]
+    return {"gemm_128x128": wide, "gemm_128x128_launches": launches_wide, "gemm_128x64": narrow, "attention": attention,
+            "total": total, "frames_per_utt": T}
+
+
+def cpu_baseline(spec, state, tfi, n_sample, length):
+    """Times the CPU oracle (oracle/allophant_oracle.py: the restatement pinned against the reference) on the host
+    cores of this box on a bounded sample of the same workload.  Reported baseline, not the target."""
+    from oracle import allophant_oracle as O
+
+    cores = max(1, (os.cpu_count() or 2) // 2)
+    torch.set_num_threads(cores)
+    audio, lengths = synthetic.make_audio(n_sample, length, seed=1234)
+    offsets = synthetic.category_offsets(spec)
+    times = []
+    frames = 0
+    for i in range(3):
+        t0 = time.perf_counter()
+        out, flen = O.predict(audio, lengths, state, spec, tfi, offsets, True)
+        dt = time.perf_counter() - t0
+        frames = int(flen.sum())
+        if i > 0:
+            times.append(dt)
+    med = sorted(times)[len(times) // 2]
+    return {"value": frames / med, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{n_sample} x {length / 16000:.0f} s utterances of the same synthetic workload, fp32 torch CPU oracle, "
+                      f"1 warm-up + median of {len(times)} runs ({med:.2f} s each)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "bf16x3", "f16", "bf16"])
+    ap.add_argument("--utterances", type=int, default=32)
+    ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--phones", type=int, default=27)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=8)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    from allophant_amd.estimator import Batch, Estimator
+    from allophant_amd import parallel
+
+    spec = build_spec()
+    state = synthetic.make_state_dict(spec, seed=0)
+    est = Estimator(spec, state, device, args.precision)
+    tfi = synthetic.make_inventory(spec, args.phones, seed=0)
+    length = int(args.seconds * 16000)
+    n = args.utterances
+    # every rank gets its own block of a notional global batch of n * world utterances
+    audio, lengths = synthetic.make_audio(n, length, seed=1234 + rank)
+    batch = Batch(audio.to(device), lengths, torch.zeros(n, dtype=torch.long))
+
+    def step(timing=False):
+        pred = est.predict(batch, tfi, True, _timing=timing)
+        if world > 1:
+            # RCCL gather of the per-frame log-probabilities (one flat fp32 block per rank) + frame lengths to rank 0
+            flat = pred._flat
+            gathered = [torch.empty_like(flat) for _ in range(world)] if rank == 0 else None
+            dist.gather(flat, gathered, dst=0)
+            lens = pred.lengths.to(device)
+            gl = [torch.empty_like(lens) for _ in range(world)] if rank == 0 else None
+            dist.gather(lens, gl, dst=0)
+            if rank == 0:
+                # `Predictions` of the global batch on rank 0: [T, n * world, C] per output
+                T = next(iter(pred.outputs.values())).shape[0]
+                outputs = {}
+                off = 0
+                done = {}
+                for name, o in pred.outputs.items():
+                    key = o.data_ptr()
+                    if key in done:
+                        outputs[name] = outputs[done[key]]
+                        continue
+                    c = o.shape[-1]
+                    first = (o.data_ptr() - flat.data_ptr()) // 4
+                    outputs[name] = torch.cat([g[first: first + T * n * c].view(T, n, c) for g in gathered], dim=1)
+                    done[key] = name
+                return outputs, torch.cat(gl)
+        return pred.outputs, pred.lengths
+
+    for _ in range(args.warmup):
+        step()
+    est.timing_fetch()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        outputs, out_lengths = step(timing=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timing = est.timing_fetch()
+
+    t_tensor = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t_tensor, op=dist.ReduceOp.MAX)
+    elapsed = float(t_tensor.item())
+
+    fl = gemm_flops(spec, n, length)
+    frames_per_rank = fl["frames_per_utt"] * n
+    total_frames = frames_per_rank * world * args.steps
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        gemm_ms, gemm_launches = timing["gemm_128x128"]
+        achieved = fl["gemm_128x128"] * args.steps / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else None
+        kernel_breakdown = {k: {"ms_per_step": round(v[0] / args.steps, 4), "launches_per_step": v[1] // max(1, args.steps)}
+                            for k, v in timing.items()}
+        pmc_path = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
+        traffic = None
+        if os.path.exists(pmc_path):
+            try:
+                with open(pmc_path) as f:
+                    rec = json.load(f)
+                if rec.get("precision") == args.precision:
+                    traffic = rec.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "encoder frames/sec (whole node), 10s x 32 utterances @16kHz",
+            "value": total_frames / elapsed,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.precision,
+            "data": "synthetic",
+            "config": {
+                "workload": f"BASELINE config 2: multitask checkpoint schema (36 attribute heads + composed phoneme head, "
+                            f"allophone pass-through), {n} x {args.seconds:.0f} s synthetic 16 kHz utterances per GPU, "
+                            f"{args.phones}-phone synthetic inventory ('es'-sized), procedural weights seed 0",
+                "global_batch": n * world,
+                "frames_per_step": frames_per_rank * world,
+                "parallelism": f"dp{world} (utterance shards + RCCL gather of log-probs to rank 0)" if world > 1 else "single GPU",
+                "precision_mode": args.precision,
+            },
+            "roofline": {
+                "kernel": "gemm_kernel<T16, planes, 128, 128, 2, 2> (conv layers 1-6, feature projection, QKV/out/FFN, wide heads)",
+                "bound": "mfma",
+                "achieved": achieved,
+                "peak": MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / MFMA_PEAK_TFLOPS if achieved else None,
+                "traffic": traffic,
+                "flops_per_launch": fl["gemm_128x128"] / fl["gemm_128x128_launches"],
+                "avg_launch_ms": gemm_ms / gemm_launches if gemm_launches else None,
+                "launches_per_step": gemm_launches // max(1, args.steps),
+            },
+            "kernels": kernel_breakdown,
+            "whole_step_tflops": fl["total"] * args.steps * world / elapsed / 1e12,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            result["cpu_baseline"] = cpu_baseline(spec, state, tfi, args.cpu_sample, length)
+        else:
+            result["cpu_baseline"] = None
+        print(json.dumps(result), flush=True)
+    est.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -48,6 +48,16 @@ extern "C" {
 #define AMX_FLAG_HOST_IO 1u      /* audio / out are host pointers; the library stages them over PCIe */
 #define AMX_FLAG_RAW_LOGITS 2u   /* `log_probabilities=False` of Estimator.predict (estimator.py:1037,1040-1046) */
 #define AMX_FLAG_KEEP_HIDDEN 4u  /* keep every encoder hidden state for amx_debug_fetch */
+#define AMX_FLAG_TIMING 8u       /* bracket every kernel launch with HIP events on the launch stream (amx_timing_fetch) */
+
+/* kernel classes reported by amx_timing_fetch */
+#define AMX_KC_GEMM_128x128 0 /* gemm_kernel<T, NT, 128, 128, 2, 2>: conv 1-6, feature projection, QKV/out/FFN, wide heads */
+#define AMX_KC_GEMM_128x64 1  /* gemm_kernel<T, NT, 128, 64, 4, 1>: grouped positional conv, narrow heads */
+#define AMX_KC_ATTENTION 2
+#define AMX_KC_ROWNORM 3
+#define AMX_KC_CONV0 4
+#define AMX_KC_OTHER 5
+#define AMX_KC_COUNT 6
 
 /* dependency codes in amx_class_desc.deps */
 #define AMX_DEP_OUTPUT (-1)                 /* "OUTPUT"   (allophant/config.py:636) */
@@ -134,17 +144,23 @@ int amx_forward(amx_handle h, const float* audio, const int64_t* lengths, int N,
                 int64_t* out_lengths, uint32_t flags, void* stream);
 int amx_synchronize(amx_handle h, void* stream);
 
-/* Replaces `GreedyCTCDecoder.__call__` (predictions.py:194-207) for every output of the last amx_forward (device
- * `out` buffer of that call): tokens/timesteps are int64 [n_outputs, N, T] (first counts[o,n] entries valid, timesteps
- * 1-based), counts int32 [n_outputs, N], scores fp32 [n_outputs, N].  All DEVICE pointers. */
-int amx_greedy_ctc(amx_handle h, const float* out, int N, int64_t L, int64_t* tokens, int64_t* timesteps,
-                   int32_t* counts, float* scores, void* stream);
+/* Replaces `GreedyCTCDecoder.__call__` (predictions.py:194-207), applied to every output of a prediction as the
+ * reference's decode loop does (run.py:767-774): `out` is the device output buffer amx_forward filled for a batch of
+ * geometry (N, L) under the current inventory, `frame_lengths` the int64 [N] HOST `Predictions.lengths`.
+ * tokens/timesteps are int64 [n_outputs, N, T] (first counts[o,n] entries valid, timesteps 1-based), counts int32
+ * [n_outputs, N], scores fp32 [n_outputs, N] (sum of the per-frame maxima); all four are DEVICE pointers. */
+int amx_greedy_ctc(amx_handle h, const float* out, const int64_t* frame_lengths, int N, int64_t L, int64_t* tokens,
+                   int64_t* timesteps, int32_t* counts, float* scores, void* stream);
 
 /* Test hook: copies an intermediate of the last amx_forward to host fp32.
  *   what = 0: conv feature extractor output [N, T, conv_dim] (after the last GELU)
  *   what = 1: hidden_states[index] [N, T, hidden]  (needs AMX_FLAG_KEEP_HIDDEN; index == layers is the final LayerNorm)
  *   what = 2: raw logits buffer [N*T, ld] (index ignored); returns ld through *ld_out */
 int amx_debug_fetch(amx_handle h, int what, int index, float* host_out, int64_t capacity, int64_t* ld_out);
+
+/* Measurement hook: sums the HIP-event durations (ms) and launch counts per kernel class (AMX_KC_*) of every
+ * amx_forward issued with AMX_FLAG_TIMING since the previous fetch; synchronises the stream. */
+int amx_timing_fetch(amx_handle h, float* ms, int32_t* launches, int n_classes);
 
 /* number of bytes of device memory held by the handle (weights + workspace) */
 int64_t amx_device_bytes(amx_handle h);

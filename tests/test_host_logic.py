@@ -1,0 +1,137 @@
+"""Host-side logic and the C-ABI surface (no compute calls: there is no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+from allophant_amd import checkpoint, lib, spec as S, synthetic
+from allophant_amd.estimator import Batch, Predictions, _spec_to_structs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    handle = lib.load()
+    header = open(os.path.join(ROOT, "include", "allophant_amx.h")).read()
+    declared = set(re.findall(r"\b(amx_[a-z_]+)\s*\(", header))
+    assert declared == set(lib.EXPORTS), declared ^ set(lib.EXPORTS)
+    for symbol in declared:
+        assert hasattr(handle, symbol), symbol
+
+
+def test_struct_layout_matches_header():
+    # sizes implied by include/allophant_amx.h (all members are 4-byte aligned scalars / arrays)
+    assert C.sizeof(lib.AmxConfig) == 4 * (3 + 8 + 8 + 6 + 1 + 5)
+    assert C.sizeof(lib.AmxClassDesc) == 48 + 4 * 3 + 4 * 64
+    assert C.sizeof(lib.AmxOutputDesc) == 48 + 4 + 4 + 8  # int32 + padding + int64
+    assert C.sizeof(lib.AmxTensor) == 24
+
+
+def test_create_without_gpu_fails_loudly():
+    """No CPU fallback: creating a model on a box without a HIP device is an error, never a silent slow path."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    handle = lib.load()
+    spec = S.baseline_spec(S.tiny_encoder(1), 5)
+    cfg, descs = _spec_to_structs(spec, "f16x3")
+    out = C.c_void_p()
+    tensors = (lib.AmxTensor * 1)()
+    tensors[0].name = b"x"
+    code = handle.amx_create(C.byref(out), 0, C.byref(cfg), descs, len(descs), tensors, 0)
+    assert code != 0 and not out.value
+    message = handle.amx_last_error(None).decode()
+    assert "no CPU fallback" in message or "HIP" in message
+
+
+def test_spec_to_structs_dependencies():
+    spec = S.hierarchical_spec(S.tiny_encoder(2), ["syllabic", "long"], embedding_size=16, train_phonemes=9, n_features=5)
+    spec["classes"][0]["dependencies"] = ["OUTPUT_1"]
+    cfg, descs = _spec_to_structs(spec, "bf16")
+    assert cfg.precision == 0 and cfg.embedding_size == 16 and cfg.n_conv == 7
+    assert descs[0].deps[0] == lib.dep_output_layer(1) == -3
+    assert list(descs[2].deps[:3]) == [lib.DEP_OUTPUT, 0, 1]
+    assert descs[2].out_features == 16 and descs[0].out_features == 4
+    with pytest.raises(ValueError):
+        _spec_to_structs(spec, "fp8")
+
+
+def test_validate_mirrors_reference_errors():
+    enc = S.tiny_encoder(1)
+    with pytest.raises(ValueError, match="duplicate"):
+        S.validate(dict(enc, classes=[{"name": "a", "size": 2, "dependencies": ["OUTPUT"]}] * 2))
+    with pytest.raises(ValueError, match="reserved"):
+        S.validate(dict(enc, classes=[{"name": "OUTPUT_1", "size": 2, "dependencies": ["OUTPUT"]}]))
+    with pytest.raises(ValueError, match="requires a dependency"):
+        S.validate(dict(enc, classes=[{"name": "a", "size": 2, "dependencies": []}]))
+    with pytest.raises(ValueError, match="requires 'OUTPUT'"):
+        S.validate(dict(enc, classes=[{"name": "a", "size": 2, "dependencies": ["b"]},
+                                      {"name": "b", "size": 2, "dependencies": ["a"]}]))
+    with pytest.raises(ValueError, match="cycle"):
+        S.validate(dict(enc, classes=[{"name": "a", "size": 2, "dependencies": ["b", "OUTPUT"]},
+                                      {"name": "b", "size": 2, "dependencies": ["a"]}]))
+
+
+def test_output_names_follow_reference_order():
+    spec = S.multitask_spec(S.tiny_encoder(1), ["x", "y"], embedding_size=16, allophone_layer=True)
+    assert S.output_names(spec) == ["x", "y", "phone", "phoneme"]
+    spec["classes"] = [
+        {"name": "phoneme", "size": 9, "dependencies": ["OUTPUT", "x", "y"]},
+        {"name": "x", "size": 3, "dependencies": ["OUTPUT_0"]},
+        {"name": "y", "size": 2, "dependencies": ["x", "OUTPUT"]},
+    ]
+    assert S.output_names(spec) == ["x", "y", "phone", "phoneme"]
+
+
+def test_synthetic_state_dict_layout_and_determinism():
+    spec = S.multitask_spec(S.xlsr_300m_encoder(), allophone_layer=True)
+    spec["layers"] = 1  # keep it small
+    sd = synthetic.make_state_dict(spec, seed=0)
+    assert sd["_acoustic_model._model.feature_extractor.conv_layers.0.conv.weight"].shape == (512, 1, 10)
+    assert sd["_acoustic_model._model.encoder.pos_conv_embed.conv.parametrizations.weight.original1"].shape == (1024, 64, 128)
+    assert sd["_projection._layers.phoneme._time_distributed_layer.weight"].shape == (640, 1024)
+    assert sd["_projection._layers.phoneme._composition_layer._attribute_embeddings.weight"].shape == (112, 640)
+    assert sd["_projection._layers.stress._time_distributed_layer.weight"].shape == (4, 1024)
+    again = synthetic.make_state_dict(spec, seed=0)
+    assert all(torch.equal(sd[k], again[k]) for k in sd)
+    other = synthetic.make_state_dict(spec, seed=1)
+    assert not torch.equal(sd["_acoustic_model._model.encoder.layer_norm.weight"],
+                           other["_acoustic_model._model.encoder.layer_norm.weight"])
+    tfi = synthetic.make_inventory(spec, 27)
+    assert tfi.shape == (27, 37) and tfi.dtype == torch.int64 and int(tfi.max()) <= 2 and int(tfi.min()) >= 0
+    assert synthetic.category_offsets(spec).tolist()[:3] == [1, 4, 7]
+
+
+def test_checkpoint_schema_round_trip(tmp_path):
+    spec = S.multitask_spec(S.tiny_encoder(2), ["syllabic", "long"], embedding_size=16, train_phonemes=9, n_features=5,
+                            allophone_layer=True)
+    spec["shared_phones"] = 11
+    sd = synthetic.make_state_dict(spec, seed=3)
+    ckpt = checkpoint.make_checkpoint(spec, sd, synthetic_encoder=True)
+    for field in ("config", "allophant_version", "feature_size", "sample_rate", "attribute_graph", "epoch",
+                  "phonetic_indexer_state", "dataset_meta_data", "model_state", "additional", "history",
+                  "optimization_states"):
+        assert field in ckpt  # reference Checkpoint fields (estimator.py:208-219)
+    path = tmp_path / "allophant.pt"
+    torch.save(ckpt, path)
+    loaded = torch.load(path, map_location="cpu", weights_only=True)
+    restored = checkpoint.spec_from_checkpoint(loaded)
+    for key in ("classes", "dependency_blanks", "embedding_size", "allophone_layer", "hidden", "layers", "shared_phones",
+                "composition_categories"):
+        assert restored[key] == spec[key], key
+    bad = dict(ckpt, sample_rate=8000)
+    with pytest.raises(ValueError, match="sampling rate"):
+        checkpoint.spec_from_checkpoint(bad)
+    # a real-model checkpoint (no encoder override) resolves to the XLS-R-300m shape
+    plain = checkpoint.make_checkpoint(S.baseline_spec(S.xlsr_300m_encoder(), 40), {}, synthetic_encoder=False)
+    assert checkpoint.spec_from_checkpoint(plain)["hidden"] == 1024
+
+
+def test_batch_and_predictions_containers():
+    b = Batch(torch.zeros(3, 10), torch.tensor([10, 4, 7]), torch.zeros(3, dtype=torch.long))
+    assert len(b) == 3 and b.size() == 3 and "Features" in repr(b)
+    moved = b.to("cpu")
+    assert isinstance(moved, Batch) and moved.audio_features.shape == (3, 10)
+    p = Predictions({"a": torch.zeros(2, 3, 4)}, torch.tensor([2, 1, 2]))
+    assert len(p) == 3 and p.task_count() == 1
