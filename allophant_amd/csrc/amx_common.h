@@ -99,6 +99,7 @@ struct GemmParams {
     int64_t ldp;
     // QKV scatter epilogue (mode 1): columns [0,D) -> Q[b,h,t,dh], [D,2D) -> K[b,h,t,dh], [2D,3D) -> Vt[b,h,dh,perm(t)]
     int mode;
+    int vec_ok;  // set by launch_gemm: N % 4 == 0 and every output row stride is a multiple of 4 elements
     void* q;
     void* k;
     void* vt;
@@ -106,6 +107,7 @@ struct GemmParams {
     int T, Tp, H, dh;
 };
 
+extern bool g_force_generic_gemm;
 void launch_gemm(int prec, const GemmParams& p, hipStream_t stream);
 // same kernel with grid.z = groups (per-group pointer advances za/zw/zbias/zout/zoutp); requires N <= 64
 void launch_gemm_grouped(int prec, const GemmParams& p, int groups, hipStream_t stream);

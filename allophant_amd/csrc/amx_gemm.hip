@@ -9,14 +9,119 @@
 // * A rows may overlap (lda < K): the strided 1-D convolutions of the wav2vec2 feature extractor and the grouped
 //   positional convolution are implicit GEMMs over channels-last activations, no im2col buffer.
 #include "amx_common.h"
+#include <type_traits>
 
 namespace amx {
+
+bool g_force_generic_gemm = false;  // developer / test switch: route every product through the generic tile kernel
 
 namespace {
 
 constexpr int BK = 64;
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// Epilogue shared by the GEMM kernels.  acc[ni][mi][r] is C[m_base + mi*16 + (lane&15)][n_base + ni*16 + 4*(lane>>4) + r].
+template <typename T, int NT, int MI, int NI>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, int z, f32x4 (&acc)[NI][MI], int m_base, int n_base, int lane) {
+    const float* bias = p.bias ? p.bias + (int64_t)z * p.zbias : nullptr;
+    const float* residual = p.residual ? p.residual + (int64_t)z * p.zout : nullptr;
+    float* out_f32 = p.out_f32 ? p.out_f32 + (int64_t)z * p.zout : nullptr;
+    T* out_p = p.out_p ? (T*)p.out_p + (int64_t)z * p.zoutp : nullptr;
+    const int D = p.H * p.dh;
+
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = m_base + mi * 16 + (lane & 15);
+        if (m >= p.M) continue;
+        bool masked = false;
+        int b = 0, t = 0;
+        if (p.row_len || p.mode == 1) {
+            int rt = p.mode == 1 ? p.T : p.rows_T;
+            b = m / rt;
+            t = m - b * rt;
+            if (p.row_len) masked = t >= p.row_len[b];
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int nb = n_base + ni * 16 + 4 * (lane >> 4);
+            if (nb >= p.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int n = nb + r;
+                float x = acc[ni][mi][r] * p.scale;
+                if (n < p.N) {
+                    if (bias) x += bias[n];
+                    if (p.act == 1) x = gelu_erf(x);
+                    if (residual) x += residual[(int64_t)m * p.ldr + n];
+                }
+                v[r] = masked ? 0.f : x;
+            }
+            if (p.mode == 1) {
+                // QKV scatter; nb % 4 == 0 and dh % 4 == 0 so the 4 columns share (which, head)
+                int which = nb / D;
+                int rem = nb - which * D;
+                int hh = rem / p.dh;
+                int d = rem - hh * p.dh;
+                T hi[4], lo[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) split16<T, NT>(v[r], hi[r], lo[r]);
+                if (which < 2) {
+                    T* dst = (T*)(which == 0 ? p.q : p.k) + (((int64_t)b * p.H + hh) * p.Tp + t) * p.dh + d;
+                    typedef typename Vec4<T>::type V4;
+                    V4 hv = {hi[0], hi[1], hi[2], hi[3]};
+                    *(V4*)dst = hv;
+                    if (NT > 1) {
+                        V4 lv = {lo[0], lo[1], lo[2], lo[3]};
+                        *(V4*)(dst + p.qk_plane) = lv;
+                    }
+                } else {
+                    T* dst = (T*)p.vt + (((int64_t)b * p.H + hh) * p.dh + d) * p.Tp + vt_perm(t);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        dst[(int64_t)r * p.Tp] = hi[r];
+                        if (NT > 1) dst[p.vt_plane + (int64_t)r * p.Tp] = lo[r];
+                    }
+                }
+                continue;
+            }
+            if (out_f32) {
+                float* dst = out_f32 + (int64_t)m * p.ldo + nb;
+                if (p.vec_ok) {
+                    *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (nb + r < p.N) dst[r] = v[r];
+                }
+            }
+            if (out_p) {
+                T* dst = out_p + (int64_t)m * p.ldp + nb;
+                T hi[4], lo[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) split16<T, NT>(v[r], hi[r], lo[r]);
+                if (p.vec_ok) {
+                    typedef typename Vec4<T>::type V4;
+                    V4 hv = {hi[0], hi[1], hi[2], hi[3]};
+                    *(V4*)dst = hv;
+                    if (NT > 1) {
+                        V4 lv = {lo[0], lo[1], lo[2], lo[3]};
+                        *(V4*)(dst + p.out_plane) = lv;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (nb + r < p.N) {
+                            dst[r] = hi[r];
+                            if (NT > 1) dst[p.out_plane + r] = lo[r];
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
 
 template <typename T, int NT, int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
@@ -35,7 +140,27 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (private 4 MiB L2 each), so the blocks that
+    // share an XCD (equal id % 8) are given one contiguous chunk of a grouped tile sequence in which 64 consecutive
+    // tiles (= the co-resident blocks of one XCD) form an 8 x 8 rectangle: every A / W panel slice fetched into that L2
+    // is reused by 8 blocks.  Pure speed: any placement gives the same results.
+    int tile_m, tile_n;
+    {
+        const int ntn = gridDim.x, ntm = gridDim.y;
+        const int total = ntn * ntm;
+        const int lin = blockIdx.x + blockIdx.y * ntn;
+        const int xcd = lin & 7, q = total >> 3, r = total & 7;
+        const int i = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);  // bijective remap
+        constexpr int GM = 8;
+        const int per_group = GM * ntn;
+        const int group = i / per_group;
+        const int first_m = group * GM;
+        const int gsize = ntm - first_m < GM ? ntm - first_m : GM;
+        const int in_group = i - group * per_group;
+        tile_m = first_m + in_group % gsize;
+        tile_n = in_group / gsize;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int z = blockIdx.z;
 
     const T* A = (const T*)p.A + (int64_t)z * p.za;
@@ -142,91 +267,398 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
     }
 
     // ---- epilogue ----
-    const float* bias = p.bias ? p.bias + (int64_t)z * p.zbias : nullptr;
-    const float* residual = p.residual ? p.residual + (int64_t)z * p.zout : nullptr;
-    float* out_f32 = p.out_f32 ? p.out_f32 + (int64_t)z * p.zout : nullptr;
-    T* out_p = p.out_p ? (T*)p.out_p + (int64_t)z * p.zoutp : nullptr;
-    const int D = p.H * p.dh;
+    gemm_epilogue<T, NT, MI, NI>(p, z, acc, m0 + wm * TM, n0 + wn * TN, lane);
+}
 
+// ---------------------------------------------------------------------------------------------------------------
+// Ping-pong GEMM for the large products (conv layers 1-6, feature projection, QKV / out-proj / FFN):
+//   256 x 256 output tile per workgroup, 8 waves = 2 groups x 4 waves (one wave of each group on every SIMD),
+//   wave tile 128 x 64 (8 x 4 accumulator fragments of v_mfma_f32_16x16x32).
+// The K dimension is consumed in "sub-steps" of 32 elements of ONE 16-bit plane: 256 A rows + 256 W rows of 64 bytes
+// = 32 KiB, DMA-ed straight into a 4-slot LDS ring with global_load_lds_dwordx4 (no staging registers, no ds_write).
+// With two planes (hi/lo split operands) the even sub-steps carry the hi planes and the odd ones the lo planes of the
+// same 32 k-values; the hi fragments stay in registers over the lo sub-step, which issues the two cross products.
+// Every wave alternates between a LOAD segment (12 ds_read_b128 fragment reads of sub-step u + its 4 DMA pieces of
+// sub-step u+3) and an MFMA segment (32 or 64 MFMAs on the fragments just read), one s_barrier after each.  The
+// second group runs one barrier behind the first, so on each SIMD one wave is always in its MFMA segment while its
+// partner reads LDS / issues DMA: the matrix pipe never waits for a load segment.
+//   visibility of sub-step v: DMA issued in load segment v-3, retired by each issuing wave's counted vmcnt at the end
+//   of its MFMA segment v-2, i.e. before barrier 2v-2 for both groups; first read in interval 2v.  Slot v%4 held
+//   sub-step v-4, last read (and waited for, lgkmcnt(0)) before barrier 2v-7; the earliest overwrite is issued after
+//   barrier 2v-7.
+// The LDS image of a DMA is lane-linear (wave-uniform base + 16 B x lane), so the bank-conflict swizzle is applied to
+// the per-lane SOURCE address and again on the fragment read (cdna_hip_programming.md rule 21).
+// Epilogue: accumulators -> per-wave LDS patch (32 x 64 fp32) -> row-major read-back, so that bias / GELU / residual /
+// row mask / 16-bit split run on 4 consecutive columns per lane and every global store instruction writes whole
+// 128 / 256-byte row segments.
+// Requires K % (128 / planes) == 0, N % 4 == 0, 16-byte aligned operand rows.
+// ---------------------------------------------------------------------------------------------------------------
+namespace pp {
+constexpr int BM = 256, BN = 256, KS = 32;
+constexpr int SLOT = 32768, W_OFF = 16384, NSLOT = 4;
+constexpr int EPI_LD = 68;                   // floats per staged epilogue row (64 + 4 pad: conflict-free b128 writes)
+constexpr int EPI_WAVE = 32 * EPI_LD * 4;    // bytes of epilogue patch per wave
+constexpr int LDS_BYTES = SLOT * NSLOT;      // 128 KiB
+}  // namespace pp
+
+// exact-GELU with erf from Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7) on v_rcp_f32 / v_exp_f32: max abs error of
+// the GELU value 4.7e-7 over [-8, 8] against float64, i.e. inside the error of an fp32 erff-based evaluation (1.2e-6).
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float ax = fabsf(x);
+    const float z = ax * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    const float e = __builtin_amdgcn_exp2f(-(z * z) * 1.4426950408889634f);
+    float q = fmaf(t, 1.061405429f, -1.453152027f);
+    q = fmaf(t, q, 1.421413741f);
+    q = fmaf(t, q, -0.284496736f);
+    q = fmaf(t, q, 0.254829592f);
+    q *= t;
+    const float erf_abs = fmaf(-q, e, 1.0f);
+    return fmaf(0.5f * ax, erf_abs, 0.5f * x);
+}
+
+template <typename T, int NT>
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
+    typedef typename Vec8<T>::type V8;
+    typedef typename Vec4<T>::type V4;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wc = wave & 3;
+
+    // XCD-aware tile order (see gemm_kernel): 32 co-resident tiles of one XCD = 8 M-tiles x 4 N-tiles.
+    int tile_m, tile_n;
+    {
+        const int ntn = gridDim.x, ntm = gridDim.y;
+        const int total = ntn * ntm;
+        const int lin = blockIdx.x + blockIdx.y * ntn;
+        const int xcd = lin & 7, q = total >> 3, r = total & 7;
+        const int i = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+        constexpr int GM = 8;
+        const int per_group = GM * ntn;
+        const int group = i / per_group;
+        const int first_m = group * GM;
+        const int gsize = ntm - first_m < GM ? ntm - first_m : GM;
+        const int in_group = i - group * per_group;
+        tile_m = first_m + in_group % gsize;
+        tile_n = in_group / gsize;
+    }
+    const int m0 = tile_m * pp::BM, n0 = tile_n * pp::BN;
+
+    // ---- DMA sources: this wave fills pieces 2*wave, 2*wave+1 (16 rows x 64 B each) of the A part and of the W part.
+    // Addresses are (wave-uniform tile base) + (32-bit per-lane byte offset): SGPR base + VGPR offset addressing keeps
+    // the per-lane state at four registers.
+    const int m0c = m0 < p.M ? m0 : p.M - 1, n0c = n0 < p.N ? n0 : p.N - 1;
+    const int64_t b0 = m0c / p.rows_per_batch;
+    const int64_t a_tile = b0 * p.a_batch_stride + (m0c - b0 * p.rows_per_batch) * p.lda;  // element offset of row m0
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.A + a_tile), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.W + (int64_t)n0c * p.ldw), 0, -1, 0x00020000);
+    uint32_t a_off[2], w_off[2];
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const int m = m0 + wm * TM + mi * 16 + (lane & 15);
-        if (m >= p.M) continue;
-        bool masked = false;
-        int b = 0, t = 0;
-        if (p.row_len || p.mode == 1) {
-            int rt = p.mode == 1 ? p.T : p.rows_T;
-            b = m / rt;
-            t = m - b * rt;
-            if (p.row_len) masked = t >= p.row_len[b];
+    for (int j = 0; j < 2; ++j) {
+        const int row = (wave * 2 + j) * 16 + (lane >> 2);
+        const int lc = (lane & 3) ^ ((row >> 2) & 2);  // logical 16-byte chunk stored at physical chunk lane & 3
+        int r = m0 + row;
+        r = r < p.M ? r : p.M - 1;
+        const int64_t b = r / p.rows_per_batch;
+        const int64_t t = r - b * p.rows_per_batch;
+        a_off[j] = (uint32_t)((b * p.a_batch_stride + t * p.lda - a_tile + lc * 8) * 2);
+        int rn = n0 + row;
+        rn = rn < p.N ? rn : p.N - 1;
+        w_off[j] = (uint32_t)(((int64_t)(rn - n0c) * p.ldw + lc * 8) * 2);
+    }
+    const uint32_t a_plane_b = (uint32_t)(p.a_plane * 2), w_plane_b = (uint32_t)(p.w_plane * 2);
+
+    // ---- fragment read offsets (bytes inside a slot) ----
+    const int rd_chunk = ((lane >> 4) ^ ((lane >> 2) & 2)) << 4;
+    const int a_rd = (grp * 128 + (lane & 15)) * 64 + rd_chunk;
+    const int w_rd = pp::W_OFF + (wc * 64 + (lane & 15)) * 64 + rd_chunk;
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    V8 fa[NT][8], fw[NT][4];
+
+    // DMA of the A part and / or W part of (plane, k-offset) into a ring slot
+    auto stage = [&](int slot, int plane, bool do_a, bool do_w, int koff) {
+        unsigned char* dst = smem + slot * pp::SLOT + wave * 2048;
+        if (do_a) {
+            const uint32_t so = plane * a_plane_b + (uint32_t)koff * 2;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_ptr_t)(dst + j * 1024), 16, a_off[j], so, 0, 0);
         }
+        if (do_w) {
+            const uint32_t so = plane * w_plane_b + (uint32_t)koff * 2;
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            const int nb = n0 + wn * TN + ni * 16 + 4 * (lane >> 4);
-            if (nb >= p.N) continue;
-            float v[4];
+            for (int j = 0; j < 2; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(dst + pp::W_OFF + j * 1024), 16, w_off[j], so, 0, 0);
+        }
+    };
+
+    // One LOAD segment + one MFMA segment.  Compile-time code: read slot RS (A and / or W fragments into plane DPL of
+    // the fragment registers), product PROD (0: W.A on plane 0, 1: lo(W).hi(A), 2: hi(W).lo(A)), and the DMA that
+    // refills, three segments ahead, the same parts of slot SS from plane SPL.
+    auto segment = [&](auto code, bool stage_ok, int stage_koff) {
+        constexpr int C = decltype(code)::value;
+        constexpr int RS = C & 3, RA = (C >> 2) & 1, RW = (C >> 3) & 1, DPL = (C >> 4) & 1, PROD = (C >> 5) & 3,
+                      SS = (C >> 7) & 3, SPL = (C >> 9) & 1;
+        // ---------------- LOAD segment ----------------
+        const unsigned char* s = smem + RS * pp::SLOT;
+        if (RA) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int n = nb + r;
-                float x = acc[ni][mi][r] * p.scale;
-                if (n < p.N) {
-                    if (bias) x += bias[n];
-                    if (p.act == 1) x = gelu_erf(x);
-                    if (residual) x += residual[(int64_t)m * p.ldr + n];
-                }
-                v[r] = masked ? 0.f : x;
-            }
-            if (p.mode == 1) {
-                // QKV scatter; nb % 4 == 0 and dh % 4 == 0 so the 4 columns share (which, head)
-                int which = nb / D;
-                int rem = nb - which * D;
-                int hh = rem / p.dh;
-                int d = rem - hh * p.dh;
-                T hi[4], lo[4];
+            for (int mi = 0; mi < 8; ++mi) fa[DPL][mi] = *(const V8*)(s + a_rd + mi * 1024);
+        }
+        if (RW) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) split16<T, NT>(v[r], hi[r], lo[r]);
-                if (which < 2) {
-                    T* dst = (T*)(which == 0 ? p.q : p.k) + (((int64_t)b * p.H + hh) * p.Tp + t) * p.dh + d;
+            for (int ni = 0; ni < 4; ++ni) fw[DPL][ni] = *(const V8*)(s + w_rd + ni * 1024);
+        }
+        if (stage_ok) stage(SS, SPL, RA, RW, stage_koff);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---------------- MFMA segment ----------------
+        __builtin_amdgcn_s_setprio(1);
+        constexpr int PW = PROD == 1 ? NT - 1 : 0, PA = PROD == 2 ? NT - 1 : 0;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        dst[r] = hi[r];
-                        if (NT > 1) dst[p.qk_plane + r] = lo[r];
-                    }
-                } else {
-                    T* dst = (T*)p.vt + (((int64_t)b * p.H + hh) * p.dh + d) * p.Tp + vt_perm(t);
+        for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        dst[(int64_t)r * p.Tp] = hi[r];
-                        if (NT > 1) dst[p.vt_plane + (int64_t)r * p.Tp] = lo[r];
-                    }
-                }
-                continue;
-            }
-            if (out_f32) {
-                float* dst = out_f32 + (int64_t)m * p.ldo + nb;
+            for (int mi = 0; mi < 8; ++mi) acc[ni][mi] = mfma16(fw[PW][ni], fa[PA][mi], acc[ni][mi]);
+        __builtin_amdgcn_s_setprio(0);
+        // retire every DMA except the one issued in this segment (same parts => same piece count)
+        if (stage_ok) {
+            if (RA && RW) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#define PP_CODE(RS, RA, RW, DPL, PROD, SS, SPL) \
+    std::integral_constant<int, (RS) | ((RA) << 2) | ((RW) << 3) | ((DPL) << 4) | ((PROD) << 5) | ((SS) << 7) | ((SPL) << 9)> {}
+
+    if constexpr (NT == 1) {
+        // segments = 32-deep K slices; slice u lives in slot u % 4
+        const int nseg = p.K / pp::KS;
+        stage(0, 0, true, true, 0);
+        stage(1, 0, true, true, pp::KS);
+        stage(2, 0, true, true, 2 * pp::KS);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // slices 0 and 1 have landed
+        __builtin_amdgcn_s_barrier();
+        if (grp == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind group 0
+        for (int u = 0; u < nseg; u += 4) {
+            segment(PP_CODE(0, 1, 1, 0, 0, 3, 0), u + 3 < nseg, (u + 3) * pp::KS);
+            segment(PP_CODE(1, 1, 1, 0, 0, 0, 0), u + 4 < nseg, (u + 4) * pp::KS);
+            segment(PP_CODE(2, 1, 1, 0, 0, 1, 0), u + 5 < nseg, (u + 5) * pp::KS);
+            segment(PP_CODE(3, 1, 1, 0, 0, 2, 0), u + 6 < nseg, (u + 6) * pp::KS);
+        }
+    } else {
+        // three segments per 32-deep K slice k: H (hi planes of A and W: hi.hi), LW (lo plane of W: lo(W).hi(A)),
+        // LA (lo plane of A: hi(W).lo(A)); hi planes of slice k in slot 2*(k%2), lo planes in slot 2*(k%2)+1.
+        const int nk = p.K / pp::KS;
+        stage(0, 0, true, true, 0);
+        stage(1, 1, false, true, 0);
+        stage(1, 1, true, false, 0);
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // H(0) and LW(0) have landed
+        __builtin_amdgcn_s_barrier();
+        if (grp == 1) __builtin_amdgcn_s_barrier();
+        for (int k = 0; k < nk; k += 2) {
+            const bool ok1 = k + 1 < nk, ok2 = k + 2 < nk;
+            segment(PP_CODE(0, 1, 1, 0, 0, 2, 0), ok1, (k + 1) * pp::KS);
+            segment(PP_CODE(1, 0, 1, 1, 1, 3, 1), ok1, (k + 1) * pp::KS);
+            segment(PP_CODE(1, 1, 0, 1, 2, 3, 1), ok1, (k + 1) * pp::KS);
+            segment(PP_CODE(2, 1, 1, 0, 0, 0, 0), ok2, (k + 2) * pp::KS);
+            segment(PP_CODE(3, 0, 1, 1, 1, 1, 1), ok2, (k + 2) * pp::KS);
+            segment(PP_CODE(3, 1, 0, 1, 2, 1, 1), ok2, (k + 2) * pp::KS);
+        }
+    }
+#undef PP_CODE
+    if (grp == 0) __builtin_amdgcn_s_barrier();  // realign the groups: every LDS read and DMA of the ring is complete
+
+#ifdef AMX_ABLATE_NO_EPI
+    if (p.M > 0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (nb + r < p.N) dst[r] = v[r];
-            }
-            if (out_p) {
-                T* dst = out_p + (int64_t)m * p.ldp + nb;
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
+#endif
+
+    // ---------------------------------------- epilogue ----------------------------------------
+    // make the lane id opaque so that no epilogue address arithmetic is hoisted above the main loop (register pressure)
+    asm volatile("" : "+v"(lane));
+    const int mw = m0 + grp * 128, nw = n0 + wc * 64;
+    if (nw >= p.N || mw >= p.M) return;
+    const int D = p.H * p.dh;
+    const float scale = p.scale;
+
+    if (p.mode == 1 && nw >= 2 * D) {
+        // V columns: transposed, key-permuted image Vt[b, h, d, perm(t)] -- written straight from the accumulator layout
+        // (a lane holds 4 consecutive d of one key; 16 consecutive lanes hold 16 consecutive keys).
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const int m = mw + mi * 16 + (lane & 15);
+            if (m >= p.M) continue;
+            const int b = m / p.T, t = m - b * p.T;
+            const bool masked = p.row_len && t >= p.row_len[b];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int n = nw + ni * 16 + 4 * (lane >> 4);
+                if (n >= p.N) continue;
+                const int rem = n - 2 * D;
+                const int hh = rem / p.dh, d = rem - hh * p.dh;
+                T* dst = (T*)p.vt + (((int64_t)b * p.H + hh) * p.dh + d) * p.Tp + vt_perm(t);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (nb + r < p.N) {
-                        T hi, lo;
-                        split16<T, NT>(v[r], hi, lo);
-                        dst[r] = hi;
-                        if (NT > 1) dst[p.out_plane + r] = lo;
+                    float x = acc[ni][mi][r] * scale;
+                    if (p.bias) x += p.bias[n + r];
+                    if (masked) x = 0.f;
+                    T hi, lo;
+                    split16<T, NT>(x, hi, lo);
+                    dst[(int64_t)r * p.Tp] = hi;
+                    if (NT > 1) dst[p.vt_plane + (int64_t)r * p.Tp] = lo;
+                }
+            }
+        }
+        return;
+    }
+
+    float* es = (float*)(smem + wave * pp::EPI_WAVE);
+    const int col = (lane & 15) * 4, rsub = lane >> 4;
+    const int n = nw + col;
+    const bool n_ok = n < p.N;  // N % 4 == 0: all four columns or none
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias && n_ok) bias4 = *(const float4*)(p.bias + n);
+    // per-lane column decomposition of the Q / K scatter
+    int64_t qk_col = 0;
+    T* qk_base = nullptr;
+    if (p.mode == 1 && n_ok) {
+        const int which = n / D;
+        const int rem = n - which * D;
+        const int hh = rem / p.dh, d = rem - hh * p.dh;
+        qk_base = (T*)(which == 0 ? p.q : p.k);
+        qk_col = (int64_t)hh * p.Tp * p.dh + d;
+    }
+    // (batch, position) of the lane's first row; rows advance by 4
+    const bool need_bt = p.row_len || p.mode == 1;
+    const int rt = p.mode == 1 ? p.T : p.rows_T;
+    int b = 0, t = 0;
+    if (need_bt) {
+        const int mfirst = mw + rsub;
+        b = mfirst / rt;
+        t = mfirst - b * rt;
+    }
+
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        // accumulator fragments 2q, 2q+1 (32 rows) -> LDS patch, fp32, row-major [32][64 (+4)]
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                *(f32x4*)(es + (h * 16 + (lane & 15)) * pp::EPI_LD + ni * 16 + 4 * (lane >> 4)) = acc[ni][2 * q + h];
+        // LDS operations of one wave complete in order: the reads below see the writes above
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int rl = i * 4 + rsub;
+            const int m = mw + q * 32 + rl;
+            const f32x4 c = *(const f32x4*)(es + rl * pp::EPI_LD + col);
+            if (m < p.M && n_ok) {
+                float v[4] = {fmaf(c[0], scale, bias4.x), fmaf(c[1], scale, bias4.y), fmaf(c[2], scale, bias4.z),
+                              fmaf(c[3], scale, bias4.w)};
+                if (p.act == 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
+                }
+                if (p.residual) {
+                    const float4 rr = *(const float4*)(p.residual + (int64_t)m * p.ldr + n);
+                    v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+                }
+                if (p.row_len && t >= p.row_len[b]) v[0] = v[1] = v[2] = v[3] = 0.f;
+                if (p.mode == 1) {
+                    T hi[4], lo[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) split16<T, NT>(v[r], hi[r], lo[r]);
+                    T* dst = qk_base + ((int64_t)b * p.H * p.Tp + t) * p.dh + qk_col;
+                    V4 hv = {hi[0], hi[1], hi[2], hi[3]};
+                    *(V4*)dst = hv;
+                    if (NT > 1) {
+                        V4 lv = {lo[0], lo[1], lo[2], lo[3]};
+                        *(V4*)(dst + p.qk_plane) = lv;
+                    }
+                } else {
+                    if (p.out_f32) *(float4*)(p.out_f32 + (int64_t)m * p.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (p.out_p) {
+                        T hi[4], lo[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) split16<T, NT>(v[r], hi[r], lo[r]);
+                        T* dst = (T*)p.out_p + (int64_t)m * p.ldp + n;
+                        V4 hv = {hi[0], hi[1], hi[2], hi[3]};
+                        *(V4*)dst = hv;
+                        if (NT > 1) {
+                            V4 lv = {lo[0], lo[1], lo[2], lo[3]};
+                            *(V4*)(dst + p.out_plane) = lv;
+                        }
                     }
                 }
+            }
+            if (need_bt) {
+                t += 4;
+                while (t >= rt) { t -= rt; ++b; }
             }
         }
     }
 }
 
 template <typename T, int NT>
+bool launch_gemm_pp(const GemmParams& p, hipStream_t stream) {
+    // eligibility: whole sub-step groups, aligned operand rows and vector epilogue, enough rows to fill the chip
+    if (g_force_generic_gemm) return false;
+    if (p.K % (128 / NT) != 0 || p.N < 256 || p.N % 4 != 0 || p.M < 1024) return false;
+    if (p.lda % 8 || p.ldw % 8 || p.a_plane % 8 || p.w_plane % 8 || p.a_batch_stride % 8) return false;
+    if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return false;
+    // DMA addressing: 32-bit byte offsets from the tile's first row; rows of a tile ascend in memory
+    if (p.M > p.rows_per_batch && (p.rows_per_batch < 256 || p.a_batch_stride < (p.rows_per_batch - 1) * p.lda)) return false;
+    {
+        const int64_t a_span = (NT > 1 ? p.a_plane : 0) + (p.M > p.rows_per_batch ? p.a_batch_stride : 0) + 256 * p.lda + p.K;
+        const int64_t w_span = (NT > 1 ? p.w_plane : 0) + 256 * p.ldw + p.K;
+        if (a_span < 0 || w_span < 0 || a_span * 2 >= (int64_t)0xFFFFFF00 || w_span * 2 >= (int64_t)0xFFFFFF00) return false;
+    }
+    if (p.bias && ((uintptr_t)p.bias & 15)) return false;
+    if (p.out_f32 && (p.ldo % 4 || ((uintptr_t)p.out_f32 & 15))) return false;
+    if (p.residual && (p.ldr % 4 || ((uintptr_t)p.residual & 15))) return false;
+    if (p.out_p && (p.ldp % 4 || p.out_plane % 4 || ((uintptr_t)p.out_p & 7))) return false;
+    if (p.mode == 1) {
+        const int D = p.H * p.dh;
+        if (D % 64 || p.dh % 4 || p.qk_plane % 4 || p.N != 3 * D) return false;
+        if (((uintptr_t)p.q & 7) || ((uintptr_t)p.k & 7)) return false;
+    } else if (p.row_len && p.rows_T <= 0) {
+        return false;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, pp::LDS_BYTES);
+        attr_set = true;
+    }
+    dim3 grid((p.N + pp::BN - 1) / pp::BN, (p.M + pp::BM - 1) / pp::BM, 1);
+    hipLaunchKernelGGL((gemm_pp_kernel<T, NT>), grid, dim3(512), pp::LDS_BYTES, stream, p);
+    return true;
+}
+
+template <typename T, int NT>
 void launch_gemm_t(const GemmParams& p, hipStream_t stream) {
     int zdim = 1;
+    if (launch_gemm_pp<T, NT>(p, stream)) return;
     // narrow outputs (grouped pos-conv, small classifier heads) use the 128x64 tile
     if (p.N <= 64) {
         constexpr int BM = 128, BN = 64;
@@ -251,7 +683,15 @@ void launch_gemm_z(const GemmParams& p, int zdim, hipStream_t stream) {
 
 }  // namespace
 
-void launch_gemm(int prec, const GemmParams& p, hipStream_t stream) {
+static GemmParams with_vec_flag(const GemmParams& in) {
+    GemmParams p = in;
+    p.vec_ok = (p.N % 4 == 0) && (!p.out_f32 || (p.ldo % 4 == 0 && p.zout % 4 == 0 && ((uintptr_t)p.out_f32 & 15) == 0)) &&
+               (!p.out_p || (p.ldp % 4 == 0 && p.zoutp % 4 == 0 && p.out_plane % 4 == 0 && ((uintptr_t)p.out_p & 7) == 0));
+    return p;
+}
+
+void launch_gemm(int prec, const GemmParams& p_in, hipStream_t stream) {
+    const GemmParams p = with_vec_flag(p_in);
     switch (prec) {
         case PREC_BF16: launch_gemm_t<bf16, 1>(p, stream); break;
         case PREC_F16: launch_gemm_t<f16, 1>(p, stream); break;
@@ -260,7 +700,8 @@ void launch_gemm(int prec, const GemmParams& p, hipStream_t stream) {
     }
 }
 
-void launch_gemm_grouped(int prec, const GemmParams& p, int groups, hipStream_t stream) {
+void launch_gemm_grouped(int prec, const GemmParams& p_in, int groups, hipStream_t stream) {
+    const GemmParams p = with_vec_flag(p_in);
     switch (prec) {
         case PREC_BF16: launch_gemm_z<bf16, 1>(p, groups, stream); break;
         case PREC_F16: launch_gemm_z<f16, 1>(p, groups, stream); break;

@@ -1,0 +1,232 @@
+// Developer micro-benchmark + self-check of the GEMM kernels of liballophant_amx (includes the translation unit directly so
+// that ablation macros apply).  Build:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iallophant_amd/csrc -Iinclude -o build/gemm_bench tools/gemm_bench.hip
+//   hipcc ... -DAMX_ABLATE_NO_EPI -o build/gemm_bench_noepi tools/gemm_bench.hip
+// Run:  build/gemm_bench check   (ping-pong kernel vs generic tile kernel on edge-case shapes)
+//       build/gemm_bench time    (model shapes of BASELINE config 2, both kernels, f16x3 and bf16)
+#include "../allophant_amd/csrc/amx_gemm.hip"
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+using namespace amx;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+
+static float f16_to_f32(unsigned short h) {
+    _Float16 v; memcpy(&v, &h, 2); return (float)v;
+}
+static float bf16_to_f32(unsigned short h) {
+    unsigned int u = (unsigned int)h << 16; float f; memcpy(&f, &u, 4); return f;
+}
+static float to_f32(int prec, unsigned short h) { return (prec == PREC_F16 || prec == PREC_F16X3) ? f16_to_f32(h) : bf16_to_f32(h); }
+
+// random 16-bit values: hi plane ~ +-[0.25, 2), lo plane ~ 2^-11 of that (f16) -- plausible split operands
+static void fill16(void* d, size_t n, int seed, int prec, bool lo_plane) {
+    std::vector<unsigned short> h(n);
+    srand(seed);
+    const bool f16 = prec == PREC_F16 || prec == PREC_F16X3;
+    for (size_t i = 0; i < n; ++i) {
+        int sign = rand() & 1;
+        if (f16) {
+            int e = (lo_plane ? 2 : 13) + rand() % 3;
+            h[i] = (unsigned short)((sign << 15) | (e << 10) | (rand() & 1023));
+        } else {
+            int e = (lo_plane ? 116 : 125) + rand() % 3;
+            h[i] = (unsigned short)((sign << 15) | (e << 7) | (rand() & 127));
+        }
+    }
+    CK(hipMemcpy(d, h.data(), n * 2, hipMemcpyHostToDevice));
+}
+static void fill32(float* d, size_t n, int seed, float scale) {
+    std::vector<float> h(n);
+    srand(seed);
+    for (size_t i = 0; i < n; ++i) h[i] = scale * ((rand() % 2001) - 1000) / 1000.f;
+    CK(hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice));
+}
+
+// fp64 reference of the dense product (operands = sum of their planes): C[m][n] = scale * sum_k A[m][k] W[n][k] + bias[n] + res[m][n]
+template <typename T>
+__global__ void ref_kernel(const T* A, int64_t a_plane, const T* W, int64_t w_plane, int NT, int M, int N, int K, float scale,
+                           const float* bias, const float* res, double* out) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
+    if (n >= N || m >= M) return;
+    double acc = 0;
+    for (int k = 0; k < K; ++k) {
+        double a = (double)(float)A[(int64_t)m * K + k], w = (double)(float)W[(int64_t)n * K + k];
+        if (NT > 1) { a += (double)(float)A[a_plane + (int64_t)m * K + k]; w += (double)(float)W[w_plane + (int64_t)n * K + k]; }
+        acc += a * w;
+    }
+    out[(int64_t)m * N + n] = acc * scale + bias[n] + (res ? (double)res[(int64_t)m * N + n] : 0.0);
+}
+
+struct Case {
+    const char* name;
+    int M, N, K;
+    int act, residual, mask, planes_out, f32_out, qkv;
+    int conv_rows_per_batch, conv_lda;  // 0: dense
+    float scale;
+};
+
+static double run_case(int prec, const Case& c, bool timing_only, double* us_pp, double* us_gen) {
+    const int NT = prec_planes(prec);
+    const int64_t rows_per_batch = c.conv_rows_per_batch ? c.conv_rows_per_batch : c.M;
+    const int64_t lda = c.conv_lda ? c.conv_lda : c.K;
+    const int64_t nbatch = (c.M + rows_per_batch - 1) / rows_per_batch;
+    const int64_t a_batch_stride = c.conv_rows_per_batch ? ((rows_per_batch - 1) * lda + c.K + 8 * 5) : 0;
+    const size_t a_el = c.conv_rows_per_batch ? (size_t)(nbatch * a_batch_stride) : (size_t)c.M * c.K;
+    const size_t w_el = (size_t)c.N * c.K;
+    const size_t o_el = (size_t)c.M * c.N;
+    void *A, *W;
+    CK(hipMalloc(&A, a_el * 2 * NT)); CK(hipMalloc(&W, w_el * 2 * NT));
+    fill16(A, a_el, 1, prec, false); fill16(W, w_el, 2, prec, false);
+    if (NT > 1) { fill16((char*)A + a_el * 2, a_el, 3, prec, true); fill16((char*)W + w_el * 2, w_el, 4, prec, true); }
+    float *bias, *res; int* row_len;
+    CK(hipMalloc(&bias, c.N * 4)); CK(hipMalloc(&res, o_el * 4));
+    fill32(bias, c.N, 5, 0.5f); fill32(res, o_el, 6, 1.0f);
+    const int T = 499, Tp = 512, dh = 64, H = c.N / 3 / dh;
+    const int nb = (c.M + T - 1) / T;
+    std::vector<int> rl(nb + 1);
+    for (int i = 0; i <= nb; ++i) rl[i] = 300 + (i * 37) % 199;
+    CK(hipMalloc(&row_len, (nb + 1) * 4)); CK(hipMemcpy(row_len, rl.data(), (nb + 1) * 4, hipMemcpyHostToDevice));
+    const size_t qk_el = (size_t)nb * H * Tp * dh;
+
+    double worst = 0;
+    std::vector<std::vector<unsigned char>> results[2];
+    for (int variant = 0; variant < 2; ++variant) {  // 0: ping-pong kernel, 1: generic kernel
+        float* outf = nullptr; void* outp = nullptr; void *q = nullptr, *k = nullptr, *vt = nullptr;
+        if (c.f32_out) { CK(hipMalloc(&outf, o_el * 4)); CK(hipMemset(outf, 0xEE, o_el * 4)); }
+        if (c.planes_out) { CK(hipMalloc(&outp, o_el * 2 * NT)); CK(hipMemset(outp, 0xEE, o_el * 2 * NT)); }
+        if (c.qkv) {
+            CK(hipMalloc(&q, qk_el * 2 * NT)); CK(hipMalloc(&k, qk_el * 2 * NT)); CK(hipMalloc(&vt, qk_el * 2 * NT));
+            CK(hipMemset(q, 0, qk_el * 2 * NT)); CK(hipMemset(k, 0, qk_el * 2 * NT)); CK(hipMemset(vt, 0, qk_el * 2 * NT));
+        }
+        GemmParams g{};
+        g.A = A; g.a_plane = a_el; g.lda = lda; g.rows_per_batch = rows_per_batch; g.a_batch_stride = a_batch_stride;
+        g.W = W; g.w_plane = w_el; g.ldw = c.K; g.M = c.M; g.N = c.N; g.K = c.K;
+        g.scale = c.scale; g.bias = bias; g.act = c.act;
+        if (c.residual) { g.residual = res; g.ldr = c.N; }
+        if (c.mask) { g.row_len = row_len; g.rows_T = T; }
+        if (c.f32_out) { g.out_f32 = outf; g.ldo = c.N; }
+        if (c.planes_out) { g.out_p = outp; g.out_plane = o_el; g.ldp = c.N; }
+        if (c.qkv) {
+            g.mode = 1; g.q = q; g.k = k; g.vt = vt; g.qk_plane = qk_el; g.vt_plane = qk_el; g.T = T; g.Tp = Tp; g.H = H; g.dh = dh;
+            g.row_len = row_len;
+        }
+        g_force_generic_gemm = variant == 1;
+        launch_gemm(prec, g, 0);
+        CK(hipDeviceSynchronize());
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        const int iters = timing_only ? 20 : 2;
+        for (int i = 0; i < 2; ++i) launch_gemm(prec, g, 0);
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < iters; ++i) launch_gemm(prec, g, 0);
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        (variant == 0 ? *us_pp : *us_gen) = ms * 1e3 / iters;
+        if (!timing_only) {
+            auto grab = [&](void* d, size_t bytes) {
+                std::vector<unsigned char> h(bytes);
+                if (d) CK(hipMemcpy(h.data(), d, bytes, hipMemcpyDeviceToHost));
+                results[variant].push_back(std::move(h));
+            };
+            grab(outf, c.f32_out ? o_el * 4 : 0);
+            grab(outp, c.planes_out ? o_el * 2 * NT : 0);
+            grab(q, c.qkv ? qk_el * 2 * NT : 0);
+            grab(k, c.qkv ? qk_el * 2 * NT : 0);
+            grab(vt, c.qkv ? qk_el * 2 * NT : 0);
+        }
+        if (outf) CK(hipFree(outf)); if (outp) CK(hipFree(outp));
+        if (q) { CK(hipFree(q)); CK(hipFree(k)); CK(hipFree(vt)); }
+    }
+    g_force_generic_gemm = false;
+    if (!timing_only) {
+        // f32 output: relative-to-magnitude error; planes: compare hi + lo as floats
+        for (size_t r = 0; r < results[0].size(); ++r) {
+            auto& x = results[0][r]; auto& y = results[1][r];
+            if (x.empty()) continue;
+            if (r == 0) {
+                const float* a = (const float*)x.data(); const float* b = (const float*)y.data();
+                for (size_t i = 0; i < x.size() / 4; ++i) {
+                    double e = fabs((double)a[i] - b[i]) / (1.0 + fabs((double)b[i]));
+                    if (!(e <= worst)) worst = (e == e) ? e : 1e30;
+                }
+            } else {
+                const unsigned short* a = (const unsigned short*)x.data(); const unsigned short* b = (const unsigned short*)y.data();
+                size_t n = x.size() / 2 / NT;
+                for (size_t i = 0; i < n; ++i) {
+                    double va = to_f32(prec, a[i]), vb = to_f32(prec, b[i]);
+                    if (NT > 1) { va += to_f32(prec, a[n + i]); vb += to_f32(prec, b[n + i]); }
+                    double e = fabs(va - vb) / (1.0 + fabs(vb));
+                    if (!(e <= worst)) worst = (e == e) ? e : 1e30;
+                }
+            }
+        }
+    }
+    if (!timing_only && c.f32_out && !c.mask && !c.act && !c.conv_rows_per_batch && !c.qkv) {
+        double* truth; CK(hipMalloc(&truth, o_el * 8));
+        dim3 grid((c.N + 127) / 128, c.M);
+        const bool is_f16 = prec == PREC_F16 || prec == PREC_F16X3;
+        if (is_f16) hipLaunchKernelGGL(ref_kernel<amx::f16>, grid, dim3(128), 0, 0, (const amx::f16*)A, (int64_t)a_el, (const amx::f16*)W, (int64_t)w_el, NT, c.M, c.N, c.K, c.scale, bias, c.residual ? res : nullptr, truth);
+        else hipLaunchKernelGGL(ref_kernel<amx::bf16>, grid, dim3(128), 0, 0, (const amx::bf16*)A, (int64_t)a_el, (const amx::bf16*)W, (int64_t)w_el, NT, c.M, c.N, c.K, c.scale, bias, c.residual ? res : nullptr, truth);
+        std::vector<double> t(o_el); CK(hipMemcpy(t.data(), truth, o_el * 8, hipMemcpyDeviceToHost));
+        double e[2] = {0, 0};
+        for (int v = 0; v < 2; ++v) {
+            const float* a = (const float*)results[v][0].data();
+            for (size_t i = 0; i < o_el; ++i) { double d = fabs((double)a[i] - t[i]) / (1.0 + fabs(t[i])); if (!(d <= e[v])) e[v] = d; }
+        }
+        printf("      vs fp64 truth: ping-pong %.3e, generic %.3e (max rel err)\n", e[0], e[1]);
+        CK(hipFree(truth));
+    }
+    CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(bias)); CK(hipFree(res)); CK(hipFree(row_len));
+    return worst;
+}
+
+int main(int argc, char** argv) {
+    const bool check = argc < 2 || !strcmp(argv[1], "check");
+    const bool timing = argc < 2 || !strcmp(argv[1], "time");
+    if (check) {
+        Case cases[] = {
+            {"dense gelu->planes, M tail", 1500, 512, 256, 1, 0, 0, 1, 0, 0, 0, 0, 1.0f},
+            {"dense f32 +res +mask, N tail", 2100, 640, 384, 0, 1, 1, 0, 1, 0, 0, 0, 0.5f},
+            {"dense f32 + planes (no bias act)", 1024, 256, 128, 0, 0, 0, 1, 1, 0, 0, 0, 1.0f},
+            {"conv-like overlapping rows", 2800, 512, 384, 0, 0, 0, 0, 1, 0, 700, 256, 1.0f},
+            {"qkv scatter", 1497, 384, 256, 0, 0, 0, 0, 0, 1, 0, 0, 1.0f},
+            {"long K", 1100, 256, 4096, 0, 1, 0, 0, 1, 0, 0, 0, 1.0f},
+        };
+        int precs[] = {PREC_F16X3, PREC_BF16X3, PREC_F16, PREC_BF16};
+        int bad = 0;
+        for (int prec : precs)
+            for (auto& c : cases) {
+                double a, b;
+                double e = run_case(prec, c, false, &a, &b);
+                // x3: both kernels are ~fp32-exact; 1 plane: identical products, different summation order + fast GELU,
+                // results quantised to 16 bit on plane outputs
+                double tol = prec_planes(prec) > 1 ? 2e-4 : ((c.planes_out || c.qkv) ? (prec == PREC_BF16 ? 8e-3 : 1e-3) : 2e-4);
+                printf("CHECK prec=%d %-36s max rel err %.3e  %s\n", prec, c.name, e, e <= tol ? "ok" : "FAIL");
+                if (!(e <= tol)) ++bad;
+            }
+        printf("gemm check: %s\n", bad ? "FAILED" : "all ok");
+        if (bad) return 1;
+    }
+    if (timing) {
+        Case shapes[] = {
+            {"ffn1 (gelu -> planes)", 15968, 4096, 1024, 1, 0, 0, 1, 0, 0, 0, 0, 1.f},
+            {"ffn2 (+res -> f32)", 15968, 1024, 4096, 0, 1, 0, 0, 1, 0, 0, 0, 1.f},
+            {"qkv (scatter)", 15968, 3072, 1024, 0, 0, 0, 0, 0, 1, 0, 0, 1.f},
+            {"out-proj (+res -> f32)", 15968, 1024, 1024, 0, 1, 0, 0, 1, 0, 0, 0, 1.f},
+            {"conv1 (f32 out)", 511968, 512, 1536, 0, 0, 0, 0, 1, 0, 15999, 1024, 1.f},
+            {"conv2 (f32 out)", 255968, 512, 1536, 0, 0, 0, 0, 1, 0, 7999, 1024, 1.f},
+        };
+        int precs[] = {PREC_F16X3, PREC_BF16, PREC_F16};
+        for (int prec : precs)
+            for (auto& c : shapes) {
+                double a = 0, b = 0;
+                run_case(prec, c, true, &a, &b);
+                double fl = 2.0 * c.M * c.N * c.K;
+                printf("TIME prec=%d %-24s M=%d N=%d K=%d : pp %.1f us %.1f TF/s | generic %.1f us %.1f TF/s  (algorithmic; x3 issues 3x)\n",
+                       prec, c.name, c.M, c.N, c.K, a, fl / a * 1e-6, b, fl / b * 1e-6);
+            }
+    }
+    return 0;
+}
