@@ -170,7 +170,7 @@ struct Timed {
     }
     ~Timed() { if (b) (void)hipEventRecord(b, h->timing_stream); }
 };
-inline int gemm_class(const GemmParams& g) { return g.N <= 64 ? AMX_KC_GEMM_128x64 : AMX_KC_GEMM_128x128; }
+inline int gemm_class(int prec, const GemmParams& g) { return gemm_uses_pp(prec, g) ? AMX_KC_GEMM_PP : AMX_KC_GEMM_TILE; }
 
 struct TensorMap {
     std::map<std::string, const amx_tensor*> m;
@@ -390,7 +390,8 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
     }
     // ---- encoder layers ----
     h->layers.resize(cfg->layers);
-    const float qscale = 1.0f / sqrtf(64.0f);
+    // folded into W_q / b_q: dh^-0.5 and log2(e) -- the attention softmax runs in base 2 (v_exp_f32)
+    const float qscale = 1.44269504088896340736f / sqrtf(64.0f);
     for (int l = 0; l < cfg->layers; ++l) {
         Layer& ly = h->layers[l];
         std::string p = AM + "encoder.layers." + std::to_string(l) + ".";
@@ -775,7 +776,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         g.M = (int)rows_out; g.N = C; g.K = C * c.conv_kernel[i];
         g.scale = 1.f; g.bias = h->conv_b[i];
         g.out_f32 = (float*)preln; g.ldo = C;
-        { Timed t_(h, gemm_class(g)); launch_gemm(prec, g, s); }
+        { Timed t_(h, gemm_class(prec, g)); launch_gemm(prec, g, s); }
         const bool last = i == c.n_conv - 1;
         const int64_t out_plane = rows_out * C;
         if (!last) {
@@ -803,7 +804,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         g.scale = 1.f; g.bias = h->fp_bias;
         g.row_len = (const int*)d_frames; g.rows_T = T;
         g.out_f32 = (float*)hbuf; g.ldo = D;
-        { Timed t_(h, gemm_class(g)); launch_gemm(prec, g, s); }
+        { Timed t_(h, gemm_class(prec, g)); launch_gemm(prec, g, s); }
     }
     // ---- positional conv embedding: h += GELU(grouped conv(h)) ----
     {
@@ -817,7 +818,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         g.M = (int)M; g.N = cg; g.K = cg * c.pos_kernel;
         g.scale = 1.f; g.bias = h->pos_b; g.zbias = cg; g.act = 1;
         g.residual = (const float*)hbuf; g.ldr = D; g.out_f32 = (float*)hbuf; g.ldo = D; g.zout = cg;
-        { Timed t_(h, AMX_KC_GEMM_128x64); launch_gemm_grouped(prec, g, c.pos_groups, s); }
+        { Timed t_(h, AMX_KC_GEMM_TILE); launch_gemm_grouped(prec, g, c.pos_groups, s); }
     }
     // ---- transformer encoder (pre-LN) ----
     const int64_t xp_plane = M * D;
@@ -832,15 +833,15 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             g.W = ly.wqkv; g.w_plane = (int64_t)3 * D * D; g.ldw = D;
             g.M = (int)M; g.N = 3 * D; g.K = D;
             g.scale = 1.f; g.bias = ly.bqkv;
-            g.mode = 1; g.q = qb; g.k = kb; g.vt = vtb;
-            g.qk_plane = (int64_t)N * H * Tp * 64; g.vt_plane = (int64_t)N * H * Tp * 64;
+            g.mode = 1; g.q = qb; g.k = kb; g.v = vtb;
+            g.qk_plane = (int64_t)N * H * Tp * 64;
             g.T = T; g.Tp = Tp; g.H = H; g.dh = 64;
-            { Timed t_(h, gemm_class(g)); launch_gemm(prec, g, s); }
+            { Timed t_(h, gemm_class(prec, g)); launch_gemm(prec, g, s); }
         }
         {
             AttnParams a{};
-            a.q = qb; a.k = kb; a.vt = vtb;
-            a.qk_plane = (int64_t)N * H * Tp * 64; a.vt_plane = (int64_t)N * H * Tp * 64;
+            a.q = qb; a.k = kb; a.v = vtb;
+            a.qk_plane = (int64_t)N * H * Tp * 64;
             a.out = ao; a.out_plane = xp_plane;
             a.frame_len = (const int*)d_frames;
             a.N = N; a.H = H; a.T = T; a.Tp = Tp; a.dh = 64;
@@ -853,7 +854,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             g.M = (int)M; g.N = D; g.K = D;
             g.scale = 1.f; g.bias = ly.bo;
             g.residual = (const float*)hbuf; g.ldr = D; g.out_f32 = (float*)hbuf; g.ldo = D;
-            { Timed t_(h, gemm_class(g)); launch_gemm(prec, g, s); }
+            { Timed t_(h, gemm_class(prec, g)); launch_gemm(prec, g, s); }
         }
         { Timed t_(h, AMX_KC_ROWNORM); launch_rownorm(prec, (const float*)hbuf, D, M, D, ly.ln2_g, ly.ln2_b, 0, nullptr, nullptr, c.eps, 0.f, xp, xp_plane, D,
                        nullptr, 0, s); }
@@ -864,7 +865,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             g.M = (int)M; g.N = F; g.K = D;
             g.scale = 1.f; g.bias = ly.b1; g.act = 1;
             g.out_p = ff; g.out_plane = M * F; g.ldp = F;
-            { Timed t_(h, gemm_class(g)); launch_gemm(prec, g, s); }
+            { Timed t_(h, gemm_class(prec, g)); launch_gemm(prec, g, s); }
         }
         {
             GemmParams g{};
@@ -873,7 +874,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             g.M = (int)M; g.N = D; g.K = F;
             g.scale = 1.f; g.bias = ly.b2;
             g.residual = (const float*)hbuf; g.ldr = D; g.out_f32 = (float*)hbuf; g.ldo = D;
-            { Timed t_(h, gemm_class(g)); launch_gemm(prec, g, s); }
+            { Timed t_(h, gemm_class(prec, g)); launch_gemm(prec, g, s); }
         }
     }
     { Timed t_(h, AMX_KC_ROWNORM); launch_rownorm(prec, (const float*)hbuf, D, M, D, h->fln_g, h->fln_b, 0, nullptr, nullptr, c.eps, 0.f, xp, xp_plane, D,
@@ -917,7 +918,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         g.scale = 1.f; g.bias = st.bias;
         if (st.composed) {
             g.out_p = ebuf; g.out_plane = M * E; g.ldp = E;
-            { Timed t_(h, gemm_class(g)); launch_gemm(prec, g, s); }
+            { Timed t_(h, gemm_class(prec, g)); launch_gemm(prec, g, s); }
             // logits = (e @ composed) / sqrt(E)   (acoustic_model.py:234)
             GemmParams g2{};
             g2.A = ebuf; g2.a_plane = M * E; g2.lda = E; g2.rows_per_batch = M;
@@ -925,10 +926,10 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             g2.M = (int)M; g2.N = h->P1; g2.K = E;
             g2.scale = 1.0f / sqrtf((float)E);
             g2.out_f32 = (float*)logits + h->col[st.classes[0]]; g2.ldo = h->ld_logits;
-            { Timed t_(h, gemm_class(g2)); launch_gemm(prec, g2, s); }
+            { Timed t_(h, gemm_class(prec, g2)); launch_gemm(prec, g2, s); }
         } else {
             g.out_f32 = (float*)logits + h->col[st.classes[0]]; g.ldo = h->ld_logits;
-            { Timed t_(h, gemm_class(g)); launch_gemm(prec, g, s); }
+            { Timed t_(h, gemm_class(prec, g)); launch_gemm(prec, g, s); }
         }
     }
     { Timed t_(h, AMX_KC_OTHER); launch_logsoftmax_out(h->out_unique_dev, (int)h->out_unique.size(), (const float*)logits, h->ld_logits, N, T,

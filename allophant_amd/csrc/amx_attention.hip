@@ -1,33 +1,48 @@
 // Flash-style multi-head self-attention with key-padding mask for gfx950 (head_dim 64), never materialising T x T.
 //
-// Per workgroup: one (utterance, head) and 128 queries (4 waves x 32).  K/V tiles of 64 keys are staged through LDS
-// (register-prefetched), scores are computed transposed, S^T = K.Q^T with v_mfma_f32_32x32x16, so that a lane owns one
-// query column: the online-softmax row statistics are lane-local (one cross-half exchange), and the exponentiated
-// accumulator registers feed the second product O^T = V^T.P directly as its B operand (accumulator-as-operand order,
-// cdna_hip_programming.md section 3) -- no LDS round trip for P.  V is consumed from a transposed image [dh][Tp] written
-// by the QKV projection epilogue with keys permuted inside groups of 16 (vt_perm) so each V fragment is one 16-byte read.
+// Per workgroup: one (utterance, head) and WAVES x 32 queries.  Q, K and V arrive row-major [N, H, Tp, 64] as 16-bit
+// planes from the QKV projection epilogue; Q already carries dh^-0.5 * log2(e), so the softmax runs on v_exp_f32
+// (exp2) with no extra multiply.
+//   * K / V tiles of 64 keys are DMA-ed straight into a double-buffered LDS ring (buffer_load ... lds, one 1-KiB piece
+//     = 8 rows x 128 B per wave-instruction, issued one tile ahead, one s_barrier per tile).  The DMA image is
+//     lane-linear, so the bank swizzles live on the per-lane SOURCE address and on the reads (rule 21):
+//       K rows: 16-byte chunk ^= (row >> 1) & 7    -> conflict-free ds_read_b128 fragment reads (16 rows, one chunk)
+//       V rows: 16-byte chunk ^= 4 * ((row >> 1) & 1) -> conflict-free ds_read_b64_tr_b16 (4 rows x 64 B per half-wave)
+//   * scores are computed transposed, S^T = K.Q^T with v_mfma_f32_32x32x16, so a lane owns one query column: the
+//     online-softmax statistics are lane-local (one cross-half exchange per tile) and the exponentiated accumulator
+//     registers feed O^T = V^T.P directly as the B operand (accumulator-as-operand order, cdna_hip_programming.md
+//     section 3); the matching V^T fragments (4 consecutive keys of one d per 64-bit half) come from the row-major V
+//     tile through the transposing LDS read ds_read_b64_tr_b16.
+//   * online softmax with a deferred maximum: the running maximum (and the O / l rescale) is only updated when some
+//     query's tile maximum exceeds it by more than 2^8; probabilities then stay <= 256, exact in the hi/lo planes.
 // Masked keys (t' >= frame_len[n]) get -inf before the softmax; key tiles past the utterance end are skipped (their
 // probabilities are exactly 0 in the reference too: finfo.min bias underflows exp to 0).
 #include "amx_common.h"
+#include <type_traits>
 
 namespace amx {
 
 namespace {
 
 constexpr int DH = 64;
-constexpr int KT = 64;   // keys per tile
-constexpr int QB = 128;  // queries per workgroup
+constexpr int KT = 64;             // keys per tile
+constexpr int TILE = KT * 128;     // bytes of one K or V tile of one plane
+constexpr float DEFER_THR = 8.0f;  // log2 units
 
-__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
-
-template <typename T, int NT>
-__global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
+template <typename T, int NT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, (WAVES * 64) / 128) void attn_kernel(const AttnParams p) {
     typedef typename Vec8<T>::type V8;
     typedef typename Vec4<T>::type V4;
-    __shared__ __attribute__((aligned(16))) unsigned char sK[NT][KT * 128];
-    __shared__ __attribute__((aligned(16))) unsigned char sV[NT][DH * 128];
+    typedef short s16x4 __attribute__((__vector_size__(8)));
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef __attribute__((address_space(3))) s16x4* lds_s4_t;
+    constexpr int QB = WAVES * 32;
+    constexpr int STAGE = NT * 2 * TILE;  // [plane][K tile | V tile]
+    constexpr int PPW = 8 / WAVES;        // DMA pieces per wave, per tile and plane (K and V each)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hh = lane >> 5, lq = lane & 31;
     const int nh = blockIdx.y;
     const int n = nh / p.H, h = nh % p.H;
@@ -38,13 +53,16 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     const int nkt = (klen + KT - 1) / KT;
 
     const T* Qb = (const T*)p.q + (int64_t)nh * p.Tp * DH;
-    const T* Kb = (const T*)p.k + (int64_t)nh * p.Tp * DH;
-    const T* Vb = (const T*)p.vt + (int64_t)nh * DH * p.Tp;
+    const __amdgpu_buffer_rsrc_t k_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.k + (int64_t)nh * p.Tp * DH), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t v_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.v + (int64_t)nh * p.Tp * DH), 0, -1, 0x00020000);
+    const uint32_t plane_b = (uint32_t)(p.qk_plane * 2);
 
     // Q fragments (B operand): lane (query, hh) holds Q[query][16ks + 8hh + j]
     V8 qf[NT][4];
     {
-        int qr = query < p.Tp ? query : p.Tp - 1;
+        const int qr = query < p.Tp ? query : p.Tp - 1;
 #pragma unroll
         for (int pl = 0; pl < NT; ++pl)
 #pragma unroll
@@ -52,45 +70,53 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
                 qf[pl][ks] = *(const V8*)(Qb + (int64_t)pl * p.qk_plane + (int64_t)qr * DH + ks * 16 + 8 * hh);
     }
 
-    // staging: K tile = 64 rows x 128 B contiguous; Vt tile = 64 rows (d) x 128 B at row stride Tp
-    const int ld_row = tid >> 3, ld_c = tid & 7;
-    uint4 rk[NT][2], rv[NT][2];
-    auto load_tile = [&](int kt) {
-        const int kb = kt * KT;
+    // ---- DMA: this wave moves pieces wave, wave + WAVES, ... (8 rows x 128 B) of every K and V tile plane ----
+    // piece parity == wave parity (WAVES is even), so the swizzled source chunk is a per-lane constant
+    const uint32_t voff_k = (uint32_t)((lane >> 3) * 128 + (((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) << 4));
+    const uint32_t voff_v = (uint32_t)((lane >> 3) * 128 + (((lane & 7) ^ (4 * ((lane >> 4) & 1))) << 4));
+    auto stage = [&](int kt, int st) {
 #pragma unroll
         for (int pl = 0; pl < NT; ++pl)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                int row = ld_row + 32 * i;
-                rk[pl][i] = *(const uint4*)(Kb + (int64_t)pl * p.qk_plane + (int64_t)(kb + row) * DH + ld_c * 8);
-                rv[pl][i] = *(const uint4*)(Vb + (int64_t)pl * p.vt_plane + (int64_t)row * p.Tp + kb + ld_c * 8);
+            for (int j = 0; j < PPW; ++j) {
+                const int piece = wave + WAVES * j;
+                const uint32_t so = (uint32_t)kt * TILE + pl * plane_b + piece * 1024;
+                unsigned char* dst = smem + st * STAGE + pl * 2 * TILE + piece * 1024;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_ptr_t)dst, 16, voff_k, so, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lds_ptr_t)(dst + TILE), 16, voff_v, so, 0, 0);
             }
     };
-    auto store_tile = [&]() {
+
+    // ---- LDS read addresses ----
+    // K fragment (c, ks): row 32c + lq, chunk (2ks + hh) ^ ((lq >> 1) & 7)
+    int kaddr[4];
 #pragma unroll
-        for (int pl = 0; pl < NT; ++pl)
+    for (int ks = 0; ks < 4; ++ks) kaddr[ks] = lq * 128 + (((2 * ks + hh) ^ ((lq >> 1) & 7)) << 4);
+    // V^T fragment half (c, s, g, dt): 16-lane group = 16 d columns x 4 keys; lane 4q + pp of the group addresses key row
+    // 32c + 16s + 8g + 4hh + q, columns 32dt + 16*((lane >> 4) & 1) + 4pp .. +3   (chunk bit 2 swizzled by (q >> 1) & 1)
+    int vaddr[2];
+    {
+        const int q4 = (lane & 15) >> 2, pp = lane & 3;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                int row = ld_row + 32 * i;
-                *(uint4*)(&sK[pl][lds_off(row, ld_c)]) = rk[pl][i];
-                *(uint4*)(&sV[pl][lds_off(row, ld_c)]) = rv[pl][i];
-            }
-    };
+        for (int dt = 0; dt < 2; ++dt)
+            vaddr[dt] = TILE + (4 * hh + q4) * 128 + 64 * (dt ^ ((q4 >> 1) & 1)) + 32 * ((lane >> 4) & 1) + 8 * pp;
+    }
 
     f32x16 O[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { O[0][r] = 0.f; O[1][r] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;
-    const float LOG2E = 1.44269504088896340736f;
 
-    load_tile(0);
-    for (int kt = 0; kt < nkt; ++kt) {
-        __syncthreads();
-        store_tile();
-        __syncthreads();
-        if (kt + 1 < nkt) load_tile(kt + 1);
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
 
-        // ---- S^T = K . Q^T : X[c][r] = score(key = kb + 32c + (r&3) + 8(r>>2) + 4hh, query) ----
+    auto tile = [&](int kt, auto stc) {
+        constexpr int ST = decltype(stc)::value;
+        if (kt + 1 < nkt) stage(kt + 1, ST ^ 1);
+        const unsigned char* sb = smem + ST * STAGE;
+
+        // ---- S^T = K . Q^T : X[c][r] = score(key = kb + 32c + (r&3) + 8(r>>2) + 4hh, query), log2 units ----
         f32x16 X[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -98,9 +124,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
             for (int r = 0; r < 16; ++r) X[c][r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                V8 kf = *(const V8*)(&sK[0][lds_off(c * 32 + lq, 2 * ks + hh)]);
+                const V8 kf = *(const V8*)(sb + c * 4096 + kaddr[ks]);
                 if (NT > 1) {
-                    V8 kl = *(const V8*)(&sK[NT - 1][lds_off(c * 32 + lq, 2 * ks + hh)]);
+                    const V8 kl = *(const V8*)(sb + 2 * TILE + c * 4096 + kaddr[ks]);
                     X[c] = mfma32(kl, qf[0][ks], X[c]);
                     X[c] = mfma32(kf, qf[NT - 1][ks], X[c]);
                 }
@@ -108,32 +134,37 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
             }
         }
         const int kb = kt * KT;
-        float mx = -INFINITY;
+        if (kb + KT > klen) {  // only the last tile holds masked keys (wave-uniform branch)
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+            for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int key = kb + 32 * c + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                float s = key < klen ? X[c][r] : -INFINITY;
-                X[c][r] = s;
-                mx = fmaxf(mx, s);
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb + 32 * c + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    X[c][r] = key < klen ? X[c][r] : -INFINITY;
+                }
+        }
+        float mx = fmaxf(X[0][0], X[1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(X[0][r], X[1][r]));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
-        m_run = m_new;
+        if (!__all(mx <= m_run + DEFER_THR)) {  // wave-uniform; both lane halves of a query see the same mx, m_run
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { O[0][r] *= alpha; O[1][r] *= alpha; }
+        }
         float psum = 0.f;
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float e = __builtin_amdgcn_exp2f((X[c][r] - m_new) * LOG2E);
+                const float e = __builtin_amdgcn_exp2f(X[c][r] - m_run);
                 X[c][r] = e;
                 psum += e;
             }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { O[0][r] *= alpha; O[1][r] *= alpha; }
+        l_run += psum;
 
         // ---- O^T += V^T . P : P's accumulator registers are the B operand ----
 #pragma unroll
@@ -148,18 +179,29 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
                     ph[j] = hi;
                     if (NT > 1) pl_[j] = lo;
                 }
-                const int chunk = 2 * (2 * c + s2) + hh;
+                const int koff = c * 4096 + s2 * 2048;  // key rows 32c + 16s2 (+ 8g)
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    V8 vf = *(const V8*)(&sV[0][lds_off(dt * 32 + lq, chunk)]);
+                    union { s16x4 h[2]; V8 v; } vf, vl;
+                    vf.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(sb + koff + vaddr[dt]));
+                    vf.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(sb + koff + 1024 + vaddr[dt]));
                     if (NT > 1) {
-                        V8 vl = *(const V8*)(&sV[NT - 1][lds_off(dt * 32 + lq, chunk)]);
-                        O[dt] = mfma32(vl, ph, O[dt]);
-                        O[dt] = mfma32(vf, pl_, O[dt]);
+                        vl.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(sb + 2 * TILE + koff + vaddr[dt]));
+                        vl.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(sb + 2 * TILE + koff + 1024 + vaddr[dt]));
+                        O[dt] = mfma32(vl.v, ph, O[dt]);
+                        O[dt] = mfma32(vf.v, pl_, O[dt]);
                     }
-                    O[dt] = mfma32(vf, ph, O[dt]);
+                    O[dt] = mfma32(vf.v, ph, O[dt]);
                 }
             }
+        // tile kt+1 has landed (this wave's pieces) and everyone is done reading tile kt
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+
+    for (int kt = 0; kt < nkt; kt += 2) {
+        tile(kt, std::integral_constant<int, 0>{});
+        if (kt + 1 < nkt) tile(kt + 1, std::integral_constant<int, 1>{});
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32);
@@ -178,22 +220,33 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
                     hv[j] = hi;
                     lv[j] = lo;
                 }
-                int d0 = dt * 32 + 8 * g + 4 * hh;
+                const int d0 = dt * 32 + 8 * g + 4 * hh;
                 *(V4*)(dst + d0) = hv;
                 if (NT > 1) *(V4*)(dst + p.out_plane + d0) = lv;
             }
     }
 }
 
+template <typename T, int NT, int WAVES>
+void launch_attn(const AttnParams& p, hipStream_t stream) {
+    constexpr int lds = 2 * NT * 2 * TILE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)attn_kernel<T, NT, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    dim3 grid((p.T + WAVES * 32 - 1) / (WAVES * 32), p.N * p.H);
+    hipLaunchKernelGGL((attn_kernel<T, NT, WAVES>), grid, dim3(WAVES * 64), lds, stream, p);
+}
+
 }  // namespace
 
 void launch_attention(int prec, const AttnParams& p, hipStream_t stream) {
-    dim3 grid((p.T + QB - 1) / QB, p.N * p.H);
     switch (prec) {
-        case PREC_BF16: hipLaunchKernelGGL((attn_kernel<bf16, 1>), grid, dim3(256), 0, stream, p); break;
-        case PREC_F16: hipLaunchKernelGGL((attn_kernel<f16, 1>), grid, dim3(256), 0, stream, p); break;
-        case PREC_BF16X3: hipLaunchKernelGGL((attn_kernel<bf16, 2>), grid, dim3(256), 0, stream, p); break;
-        default: hipLaunchKernelGGL((attn_kernel<f16, 2>), grid, dim3(256), 0, stream, p); break;
+        case PREC_BF16: launch_attn<bf16, 1, 8>(p, stream); break;
+        case PREC_F16: launch_attn<f16, 1, 8>(p, stream); break;
+        case PREC_BF16X3: launch_attn<bf16, 2, 8>(p, stream); break;
+        default: launch_attn<f16, 2, 8>(p, stream); break;
     }
 }
 

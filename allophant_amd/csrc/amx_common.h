@@ -97,18 +97,20 @@ struct GemmParams {
     void* out_p;  // 16-bit planes
     int64_t out_plane;
     int64_t ldp;
-    // QKV scatter epilogue (mode 1): columns [0,D) -> Q[b,h,t,dh], [D,2D) -> K[b,h,t,dh], [2D,3D) -> Vt[b,h,dh,perm(t)]
+    // QKV scatter epilogue (mode 1): columns [0,D) -> Q[b,h,t,dh], [D,2D) -> K[b,h,t,dh], [2D,3D) -> V[b,h,t,dh]
     int mode;
     int vec_ok;  // set by launch_gemm: N % 4 == 0 and every output row stride is a multiple of 4 elements
     void* q;
     void* k;
-    void* vt;
-    int64_t qk_plane, vt_plane;
+    void* v;
+    int64_t qk_plane;  // plane distance of q, k and v
     int T, Tp, H, dh;
 };
 
 extern bool g_force_generic_gemm;
 void launch_gemm(int prec, const GemmParams& p, hipStream_t stream);
+// true when launch_gemm routes this product to the 256x256 ping-pong kernel (else: generic tile kernel)
+bool gemm_uses_pp(int prec, const GemmParams& p);
 // same kernel with grid.z = groups (per-group pointer advances za/zw/zbias/zout/zoutp); requires N <= 64
 void launch_gemm_grouped(int prec, const GemmParams& p, int groups, hipStream_t stream);
 
@@ -116,22 +118,16 @@ void launch_gemm_grouped(int prec, const GemmParams& p, int groups, hipStream_t 
 // attention
 // ---------------------------------------------------------------------------------------------------------------
 struct AttnParams {
-    const void* q;  // [N,H,Tp,dh] planes (already scaled by dh^-0.5)
+    const void* q;  // [N,H,Tp,dh] planes, already scaled by dh^-0.5 * log2(e)
     const void* k;  // [N,H,Tp,dh]
-    const void* vt; // [N,H,dh,Tp], key index permuted inside aligned groups of 16 (see vt_perm)
-    int64_t qk_plane, vt_plane;
+    const void* v;  // [N,H,Tp,dh]; rows [T, Tp) of all three must be finite (zero)
+    int64_t qk_plane;
     void* out;  // [N*T, D] planes, column h*dh + d
     int64_t out_plane;
     const int* frame_len;  // [N] valid keys per utterance
     int N, H, T, Tp, dh;
 };
 void launch_attention(int prec, const AttnParams& p, hipStream_t stream);
-
-// position of key t inside the transposed V image: bits 2 and 3 of t swapped, so that the 8 keys a lane needs for one
-// 32x32x16 MFMA k-step (accumulator-as-operand order, cdna_hip_programming.md section 3) are 16 contiguous bytes.
-__host__ __device__ __forceinline__ int vt_perm(int t) {
-    return (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1);
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // row-wise / elementwise kernels (amx_rowops.hip)

@@ -67,21 +67,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, int z, f32x4 
                 T hi[4], lo[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) split16<T, NT>(v[r], hi[r], lo[r]);
-                if (which < 2) {
-                    T* dst = (T*)(which == 0 ? p.q : p.k) + (((int64_t)b * p.H + hh) * p.Tp + t) * p.dh + d;
+                {
+                    T* dst = (T*)(which == 0 ? p.q : (which == 1 ? p.k : p.v)) + (((int64_t)b * p.H + hh) * p.Tp + t) * p.dh + d;
                     typedef typename Vec4<T>::type V4;
                     V4 hv = {hi[0], hi[1], hi[2], hi[3]};
                     *(V4*)dst = hv;
                     if (NT > 1) {
                         V4 lv = {lo[0], lo[1], lo[2], lo[3]};
                         *(V4*)(dst + p.qk_plane) = lv;
-                    }
-                } else {
-                    T* dst = (T*)p.vt + (((int64_t)b * p.H + hh) * p.dh + d) * p.Tp + vt_perm(t);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        dst[(int64_t)r * p.Tp] = hi[r];
-                        if (NT > 1) dst[p.vt_plane + (int64_t)r * p.Tp] = lo[r];
                     }
                 }
                 continue;
@@ -317,6 +310,126 @@ __device__ __forceinline__ float gelu_fast(float x) {
     return fmaf(0.5f * ax, erf_abs, 0.5f * x);
 }
 
+// In-place MFMA (accumulator tied to its own registers).  With the builtin, hipcc gives every result a fresh register
+// quad; at ~200 live registers the resulting tuple fragmentation spills into the main loop, and a scratch reload's
+// s_waitcnt vmcnt(0) would drain the LDS-DMA ring.  Operands come straight from ds_read (the compiler places the
+// lgkmcnt wait); independent accumulators issue back to back; the epilogue waits out the MFMA latency explicitly.
+__device__ __forceinline__ void mfma16_acc(f32x4& c, f16x8 a, f16x8 b) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma16_acc(f32x4& c, bf16x8 a, bf16x8 b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+
+// ---- branch-free epilogues for interior wave blocks (all 128 x 64 outputs in range, no row mask) ----
+// stage accumulator fragments 2q, 2q+1 (32 rows x 64 columns) of the wave block into its fp32 LDS patch
+__device__ __forceinline__ void pp_stage_round(float* es, f32x4 (&acc)[4][8], int q, int lane) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+            *(f32x4*)(es + (h * 16 + (lane & 15)) * pp::EPI_LD + ni * 16 + 4 * (lane >> 4)) = acc[ni][2 * q + h];
+}
+
+// fp32 output (+ bias, + residual): a lane owns 4 consecutive columns; 16 lanes cover a 256-byte row segment.
+// All loads of a 32-row round are issued before the first use, all stores after: no wait inside the round.
+template <bool RES>
+__device__ __forceinline__ void pp_epilogue_f32(const GemmParams& p, f32x4 (&acc)[4][8], float* es, int lane, int mw, int nw) {
+    const int col = (lane & 15) * 4, rsub = lane >> 4;
+    const int n = nw + col;
+    const float scale = p.scale;
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) b4 = *(const float4*)(p.bias + n);
+    float* optr = p.out_f32 + (int64_t)(mw + rsub) * p.ldo + n;
+    const float* rptr = RES ? p.residual + (int64_t)(mw + rsub) * p.ldr + n : nullptr;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float4 r[8];
+        if (RES) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) r[i] = *(const float4*)(rptr + (int64_t)(q * 32 + i * 4) * p.ldr);
+        }
+        pp_stage_round(es, acc, q, lane);
+        f32x4 c[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c[i] = *(const f32x4*)(es + (i * 4 + rsub) * pp::EPI_LD + col);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float4 v = make_float4(fmaf(c[i][0], scale, b4.x), fmaf(c[i][1], scale, b4.y), fmaf(c[i][2], scale, b4.z),
+                                   fmaf(c[i][3], scale, b4.w));
+            if (RES) { v.x += r[i].x; v.y += r[i].y; v.z += r[i].z; v.w += r[i].w; }
+            *(float4*)(optr + (int64_t)(q * 32 + i * 4) * p.ldo) = v;
+        }
+    }
+}
+
+// 16-bit plane output (+ bias, optional GELU), or the Q / K / V scatter of the fused QKV projection (QK): a lane owns 8
+// consecutive columns (one 16-byte store per plane); 8 lanes cover the 128-byte row segment of the wave block.
+template <typename T, int NT, bool ACT, bool QK>
+__device__ __forceinline__ void pp_epilogue_p16(const GemmParams& p, f32x4 (&acc)[4][8], float* es, int lane, int mw, int nw) {
+    typedef typename Vec8<T>::type V8;
+    const int col = (lane & 7) * 8, rs = lane >> 3;
+    const int n = nw + col;
+    const float scale = p.scale;
+    float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+    if (p.bias) { b0 = *(const float4*)(p.bias + n); b1 = *(const float4*)(p.bias + n + 4); }
+    T* base;
+    int64_t row_stride, plane;
+    int b = 0, t = 0;
+    if (QK) {
+        const int D = p.H * p.dh;
+        const int which = n / D;
+        const int rem = n - which * D;
+        const int hh = rem / p.dh, d = rem - hh * p.dh;
+        base = (T*)(which == 0 ? p.q : (which == 1 ? p.k : p.v)) + (int64_t)hh * p.Tp * p.dh + d;
+        row_stride = p.dh;
+        plane = p.qk_plane;
+        b = (mw + rs) / p.T;
+        t = (mw + rs) - b * p.T;
+    } else {
+        base = (T*)p.out_p + (int64_t)(mw + rs) * p.ldp + n;
+        row_stride = p.ldp;
+        plane = p.out_plane;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        pp_stage_round(es, acc, q, lane);
+        f32x4 c[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            c[i][0] = *(const f32x4*)(es + (i * 8 + rs) * pp::EPI_LD + col);
+            c[i][1] = *(const f32x4*)(es + (i * 8 + rs) * pp::EPI_LD + col + 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v[8] = {fmaf(c[i][0][0], scale, b0.x), fmaf(c[i][0][1], scale, b0.y), fmaf(c[i][0][2], scale, b0.z),
+                          fmaf(c[i][0][3], scale, b0.w), fmaf(c[i][1][0], scale, b1.x), fmaf(c[i][1][1], scale, b1.y),
+                          fmaf(c[i][1][2], scale, b1.z), fmaf(c[i][1][3], scale, b1.w)};
+            V8 hv, lv;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                float x = ACT ? gelu_fast(v[r]) : v[r];
+                T hi, lo = (T)0.f;
+                split16<T, NT>(x, hi, lo);
+                hv[r] = hi;
+                lv[r] = lo;
+            }
+            T* dst;
+            if (QK) {
+                dst = base + ((int64_t)b * p.H * p.Tp + t) * row_stride;
+                t += 8;  // rows advance by 8; T >= 8 here
+                const bool wrap = t >= p.T;
+                t -= wrap ? p.T : 0;
+                b += wrap ? 1 : 0;
+            } else {
+                dst = base + (int64_t)(q * 32 + i * 8) * row_stride;
+            }
+            *(V8*)dst = hv;
+            if (NT > 1) *(V8*)(dst + plane) = lv;
+        }
+    }
+}
+
 template <typename T, int NT>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     typedef typename Vec8<T>::type V8;
@@ -430,7 +543,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-            for (int mi = 0; mi < 8; ++mi) acc[ni][mi] = mfma16(fw[PW][ni], fa[PA][mi], acc[ni][mi]);
+            for (int mi = 0; mi < 8; ++mi) mfma16_acc(acc[ni][mi], fw[PW][ni], fa[PA][mi]);
         __builtin_amdgcn_s_setprio(0);
         // retire every DMA except the one issued in this segment (same parts => same piece count)
         if (stage_ok) {
@@ -483,6 +596,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     }
 #undef PP_CODE
     if (grp == 0) __builtin_amdgcn_s_barrier();  // realign the groups: every LDS read and DMA of the ring is complete
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // MFMA results -> VALU / LDS readers (the MFMAs are inline asm)
 
 #ifdef AMX_ABLATE_NO_EPI
     if (p.M > 0) {
@@ -502,38 +616,24 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     const int D = p.H * p.dh;
     const float scale = p.scale;
 
-    if (p.mode == 1 && nw >= 2 * D) {
-        // V columns: transposed, key-permuted image Vt[b, h, d, perm(t)] -- written straight from the accumulator layout
-        // (a lane holds 4 consecutive d of one key; 16 consecutive lanes hold 16 consecutive keys).
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-            const int m = mw + mi * 16 + (lane & 15);
-            if (m >= p.M) continue;
-            const int b = m / p.T, t = m - b * p.T;
-            const bool masked = p.row_len && t >= p.row_len[b];
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const int n = nw + ni * 16 + 4 * (lane >> 4);
-                if (n >= p.N) continue;
-                const int rem = n - 2 * D;
-                const int hh = rem / p.dh, d = rem - hh * p.dh;
-                T* dst = (T*)p.vt + (((int64_t)b * p.H + hh) * p.dh + d) * p.Tp + vt_perm(t);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float x = acc[ni][mi][r] * scale;
-                    if (p.bias) x += p.bias[n + r];
-                    if (masked) x = 0.f;
-                    T hi, lo;
-                    split16<T, NT>(x, hi, lo);
-                    dst[(int64_t)r * p.Tp] = hi;
-                    if (NT > 1) dst[p.vt_plane + (int64_t)r * p.Tp] = lo;
-                }
-            }
-        }
-        return;
-    }
-
     float* es = (float*)(smem + wave * pp::EPI_WAVE);
+    if (mw + 128 <= p.M && nw + 64 <= p.N && !p.row_len && p.vec_ok) {
+        // interior block: branch-free epilogues
+        if (p.mode == 1) {
+            if (p.T >= 8 && p.dh % 8 == 0 && p.qk_plane % 8 == 0 && !(((uintptr_t)p.q | (uintptr_t)p.k | (uintptr_t)p.v) & 15)) {
+                pp_epilogue_p16<T, NT, false, true>(p, acc, es, lane, mw, nw);
+                return;
+            }
+        } else if (p.out_f32 && !p.out_p && p.act == 0) {
+            if (p.residual) pp_epilogue_f32<true>(p, acc, es, lane, mw, nw);
+            else pp_epilogue_f32<false>(p, acc, es, lane, mw, nw);
+            return;
+        } else if (p.out_p && !p.out_f32 && !p.residual && p.ldp % 8 == 0 && p.out_plane % 8 == 0 && !((uintptr_t)p.out_p & 15)) {
+            if (p.act == 1) pp_epilogue_p16<T, NT, true, false>(p, acc, es, lane, mw, nw);
+            else pp_epilogue_p16<T, NT, false, false>(p, acc, es, lane, mw, nw);
+            return;
+        }
+    }
     const int col = (lane & 15) * 4, rsub = lane >> 4;
     const int n = nw + col;
     const bool n_ok = n < p.N;  // N % 4 == 0: all four columns or none
@@ -546,7 +646,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         const int which = n / D;
         const int rem = n - which * D;
         const int hh = rem / p.dh, d = rem - hh * p.dh;
-        qk_base = (T*)(which == 0 ? p.q : p.k);
+        qk_base = (T*)(which == 0 ? p.q : (which == 1 ? p.k : p.v));
         qk_col = (int64_t)hh * p.Tp * p.dh + d;
     }
     // (batch, position) of the lane's first row; rows advance by 4
@@ -620,8 +720,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     }
 }
 
-template <typename T, int NT>
-bool launch_gemm_pp(const GemmParams& p, hipStream_t stream) {
+bool pp_eligible(int NT, const GemmParams& p) {
     // eligibility: whole sub-step groups, aligned operand rows and vector epilogue, enough rows to fill the chip
     if (g_force_generic_gemm) return false;
     if (p.K % (128 / NT) != 0 || p.N < 256 || p.N % 4 != 0 || p.M < 1024) return false;
@@ -641,10 +740,16 @@ bool launch_gemm_pp(const GemmParams& p, hipStream_t stream) {
     if (p.mode == 1) {
         const int D = p.H * p.dh;
         if (D % 64 || p.dh % 4 || p.qk_plane % 4 || p.N != 3 * D) return false;
-        if (((uintptr_t)p.q & 7) || ((uintptr_t)p.k & 7)) return false;
+        if (((uintptr_t)p.q & 7) || ((uintptr_t)p.k & 7) || ((uintptr_t)p.v & 7)) return false;
     } else if (p.row_len && p.rows_T <= 0) {
         return false;
     }
+    return true;
+}
+
+template <typename T, int NT>
+bool launch_gemm_pp(const GemmParams& p, hipStream_t stream) {
+    if (!pp_eligible(NT, p)) return false;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, pp::LDS_BYTES);
@@ -689,6 +794,8 @@ static GemmParams with_vec_flag(const GemmParams& in) {
                (!p.out_p || (p.ldp % 4 == 0 && p.zoutp % 4 == 0 && p.out_plane % 4 == 0 && ((uintptr_t)p.out_p & 7) == 0));
     return p;
 }
+
+bool gemm_uses_pp(int prec, const GemmParams& p_in) { return pp_eligible(prec_planes(prec), with_vec_flag(p_in)); }
 
 void launch_gemm(int prec, const GemmParams& p_in, hipStream_t stream) {
     const GemmParams p = with_vec_flag(p_in);

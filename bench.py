@@ -40,31 +40,39 @@ def build_spec():
     return spec
 
 
-def gemm_flops(spec, n, length):
-    """Algorithmic FLOPs per step of the launches of each GEMM kernel instance (SURVEY.md Appendix D formulas)."""
+def gemm_flops(spec, n, length, planes):
+    """Algorithmic FLOPs per step of the launches of each GEMM kernel (SURVEY.md Appendix D formulas).  The routing rule
+    mirrors ``pp_eligible`` in allophant_amd/csrc/amx_gemm.hip: the 256 x 256 ping-pong kernel takes every product with
+    N >= 256, N % 4 == 0, M >= 1024 and K a multiple of 128 / planes; the generic tile kernel takes the rest."""
     C, D, F = spec["conv_dim"], spec["hidden"], spec["ffn"]
     ts = [length]
     for k, s in zip(spec["conv_kernel"], spec["conv_stride"]):
         ts.append((ts[-1] - k) // s + 1)
     T = ts[-1]
     M = n * T
-    wide = 0
-    launches_wide = 0
+    products = []  # (M, N, K, launches)
     for i in range(1, len(spec["conv_kernel"])):
-        wide += 2 * n * ts[i + 1] * C * C * spec["conv_kernel"][i]
-        launches_wide += 1
-    wide += 2 * M * C * D
-    launches_wide += 1
-    wide += spec["layers"] * 2 * M * (3 * D * D + D * D + 2 * D * F)
-    launches_wide += 4 * spec["layers"]
+        products.append((n * ts[i + 1], C, C * spec["conv_kernel"][i], 1))
+    products.append((M, D, C, 1))
+    for shape in ((3 * D, D), (D, D), (F, D), (D, F)):
+        products.append((M, shape[0], shape[1], spec["layers"]))
     attr_cols = sum(c["size"] + 1 for c in spec["classes"] if c["name"] != "phoneme")
-    wide += 2 * M * D * attr_cols + 2 * M * D * spec["embedding_size"]
-    launches_wide += 2
-    narrow = 2 * M * D * (D // spec["pos_groups"]) * spec["pos_kernel"]
+    products.append((M, attr_cols, D, 1))
+    products.append((M, spec["embedding_size"], D, 1))
+    pp = tile = 0
+    pp_launches = 0
+    for m, nn, k, cnt in products:
+        fl = 2 * m * nn * k * cnt
+        if nn >= 256 and nn % 4 == 0 and m >= 1024 and k % (128 // planes) == 0:
+            pp += fl
+            pp_launches += cnt
+        else:
+            tile += fl
+    tile += 2 * M * D * (D // spec["pos_groups"]) * spec["pos_kernel"]  # grouped positional conv
     attention = spec["layers"] * 4 * M * T * D
-    total = wide + narrow + attention + 2 * n * ts[1] * C * spec["conv_kernel"][0]
-    return {"gemm_128x128": wide, "gemm_128x128_launches": launches_wide, "gemm_128x64": narrow, "attention": attention,
-            "total": total, "frames_per_utt": T}
+    total = pp + tile + attention + 2 * n * ts[1] * C * spec["conv_kernel"][0]
+    return {"gemm_pp": pp, "gemm_pp_launches": pp_launches, "gemm_tile": tile, "attention": attention, "total": total,
+            "frames_per_utt": T}
 
 
 def cpu_baseline(spec, state, tfi, n_sample, length):
@@ -181,13 +189,14 @@ def main():
         dist.all_reduce(t_tensor, op=dist.ReduceOp.MAX)
     elapsed = float(t_tensor.item())
 
-    fl = gemm_flops(spec, n, length)
+    planes = 2 if args.precision.endswith("x3") else 1
+    fl = gemm_flops(spec, n, length, planes)
     frames_per_rank = fl["frames_per_utt"] * n
     total_frames = frames_per_rank * world * args.steps
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        gemm_ms, gemm_launches = timing["gemm_128x128"]
-        achieved = fl["gemm_128x128"] * args.steps / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else None
+        gemm_ms, gemm_launches = timing["gemm_pp"]
+        achieved = fl["gemm_pp"] * args.steps / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else None
         kernel_breakdown = {k: {"ms_per_step": round(v[0] / args.steps, 4), "launches_per_step": v[1] // max(1, args.steps)}
                             for k, v in timing.items()}
         pmc_path = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
@@ -223,14 +232,15 @@ def main():
                 "precision_mode": args.precision,
             },
             "roofline": {
-                "kernel": "gemm_kernel<T16, planes, 128, 128, 2, 2> (conv layers 1-6, feature projection, QKV/out/FFN, wide heads)",
+                "kernel": "gemm_pp_kernel<T16, planes> 256x256 ping-pong GEMM (conv layers 1-6, feature projection, QKV/out/FFN, phoneme head)",
+                "mfma_issue_factor": 3 if planes == 2 else 1,
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / MFMA_PEAK_TFLOPS if achieved else None,
                 "traffic": traffic,
-                "flops_per_launch": fl["gemm_128x128"] / fl["gemm_128x128_launches"],
+                "flops_per_launch": fl["gemm_pp"] / fl["gemm_pp_launches"],
                 "avg_launch_ms": gemm_ms / gemm_launches if gemm_launches else None,
                 "launches_per_step": gemm_launches // max(1, args.steps),
             },

@@ -110,7 +110,7 @@ static double run_case(int prec, const Case& c, bool timing_only, double* us_pp,
         if (c.f32_out) { g.out_f32 = outf; g.ldo = c.N; }
         if (c.planes_out) { g.out_p = outp; g.out_plane = o_el; g.ldp = c.N; }
         if (c.qkv) {
-            g.mode = 1; g.q = q; g.k = k; g.vt = vt; g.qk_plane = qk_el; g.vt_plane = qk_el; g.T = T; g.Tp = Tp; g.H = H; g.dh = dh;
+            g.mode = 1; g.q = q; g.k = k; g.v = vt; g.qk_plane = qk_el; g.T = T; g.Tp = Tp; g.H = H; g.dh = dh;
             g.row_len = row_len;
         }
         g_force_generic_gemm = variant == 1;
