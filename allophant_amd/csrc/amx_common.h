@@ -54,17 +54,45 @@ __device__ __forceinline__ void split16(float x, T& hi, T& lo) {
     }
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// exact-GELU with erf from Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7) on v_rcp_f32 / v_exp_f32: max abs error of
+// the GELU value 4.7e-7 over [-8, 8] against float64, i.e. inside the error of an fp32 erff-based evaluation (1.2e-6),
+// at about a third of the instructions (no branches).
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float ax = fabsf(x);
+    const float z = ax * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    const float e = __builtin_amdgcn_exp2f(-(z * z) * 1.4426950408889634f);
+    float q = fmaf(t, 1.061405429f, -1.453152027f);
+    q = fmaf(t, q, 1.421413741f);
+    q = fmaf(t, q, -0.284496736f);
+    q = fmaf(t, q, 0.254829592f);
+    q *= t;
+    const float erf_abs = fmaf(-q, e, 1.0f);
+    return fmaf(0.5f * ax, erf_abs, 0.5f * x);
+}
 
+// 64-lane reductions on the DPP cross-lane network (no LDS crossbar round trips): butterfly inside each row of 16 lanes
+// (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror), then the four row totals via v_readlane.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float lane_value(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += dpp_move<0xB1>(v);
+    v += dpp_move<0x4E>(v);
+    v += dpp_move<0x141>(v);
+    v += dpp_move<0x140>(v);
+    return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+    v = fmaxf(v, dpp_move<0xB1>(v));
+    v = fmaxf(v, dpp_move<0x4E>(v));
+    v = fmaxf(v, dpp_move<0x141>(v));
+    v = fmaxf(v, dpp_move<0x140>(v));
+    return fmaxf(fmaxf(lane_value(v, 0), lane_value(v, 16)), fmaxf(lane_value(v, 32), lane_value(v, 48)));
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -105,6 +133,7 @@ struct GemmParams {
     void* v;
     int64_t qk_plane;  // plane distance of q, k and v
     int T, Tp, H, dh;
+    unsigned long long* stamps;  // developer diagnostic (-DAMX_PP_STAMP builds of tools/gemm_bench.hip), else null
 };
 
 extern bool g_force_generic_gemm;

@@ -53,7 +53,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, int z, f32x4 
                 float x = acc[ni][mi][r] * p.scale;
                 if (n < p.N) {
                     if (bias) x += bias[n];
-                    if (p.act == 1) x = gelu_erf(x);
+                    if (p.act == 1) x = gelu_fast(x);
                     if (residual) x += residual[(int64_t)m * p.ldr + n];
                 }
                 v[r] = masked ? 0.f : x;
@@ -264,51 +264,42 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Ping-pong GEMM for the large products (conv layers 1-6, feature projection, QKV / out-proj / FFN):
-//   256 x 256 output tile per workgroup, 8 waves = 2 groups x 4 waves (one wave of each group on every SIMD),
-//   wave tile 128 x 64 (8 x 4 accumulator fragments of v_mfma_f32_16x16x32).
+// Ping-pong GEMM for the large products (conv layers 1-6, feature projection, QKV / out-proj / FFN, phoneme head):
+//   persistent workgroups (one per CU) walk 256 x 256 output tiles; 8 waves = 2 groups x 4 waves (one wave of each
+//   group on every SIMD), wave tile 128 x 64 (8 x 4 accumulator fragments of v_mfma_f32_16x16x32).
 // The K dimension is consumed in "sub-steps" of 32 elements of ONE 16-bit plane: 256 A rows + 256 W rows of 64 bytes
-// = 32 KiB, DMA-ed straight into a 4-slot LDS ring with global_load_lds_dwordx4 (no staging registers, no ds_write).
-// With two planes (hi/lo split operands) the even sub-steps carry the hi planes and the odd ones the lo planes of the
-// same 32 k-values; the hi fragments stay in registers over the lo sub-step, which issues the two cross products.
-// Every wave alternates between a LOAD segment (12 ds_read_b128 fragment reads of sub-step u + its 4 DMA pieces of
-// sub-step u+3) and an MFMA segment (32 or 64 MFMAs on the fragments just read), one s_barrier after each.  The
-// second group runs one barrier behind the first, so on each SIMD one wave is always in its MFMA segment while its
-// partner reads LDS / issues DMA: the matrix pipe never waits for a load segment.
-//   visibility of sub-step v: DMA issued in load segment v-3, retired by each issuing wave's counted vmcnt at the end
-//   of its MFMA segment v-2, i.e. before barrier 2v-2 for both groups; first read in interval 2v.  Slot v%4 held
-//   sub-step v-4, last read (and waited for, lgkmcnt(0)) before barrier 2v-7; the earliest overwrite is issued after
-//   barrier 2v-7.
+// = 32 KiB, DMA-ed straight into a 4-slot LDS ring with buffer_load_dwordx4 ... lds (no staging registers, no
+// ds_write; SGPR descriptor + 32-bit per-lane offset, so the per-lane DMA state is four registers).
+// With two planes (hi/lo split operands) a 32-deep K slice takes three segments: H (hi planes of A and W: hi.hi),
+// LW (lo plane of W: lo(W).hi(A)) and LA (lo plane of A: hi(W).lo(A)); the hi fragments stay in registers.
+// Every wave alternates between a LOAD segment (ds_read_b128 fragment reads of sub-step u + its DMA pieces of
+// sub-step u+3) and an MFMA segment (32 MFMAs on the fragments just read), one s_barrier after each.  The second
+// group runs one barrier behind the first, so on each SIMD one wave is in its MFMA segment while its partner reads
+// LDS / issues DMA: the matrix pipe does not wait for a load segment.
+//   visibility of sub-step v: DMA issued in LOAD segment v-3; each issuing wave retires it with a counted vmcnt that
+//   leaves only the pieces of sub-steps v+1, v+2 in flight -- group 0 at the end of its MFMA segment v-1, group 1 at
+//   the end of its LOAD segment v-1 -- i.e. before barrier 2v-1 for both groups; first read in interval 2v.
+//   Slot v%4 held sub-step v-4, last read (and waited for, lgkmcnt(0)) before barrier 2v-7; the earliest overwrite is
+//   issued after barrier 2v-7.
 // The LDS image of a DMA is lane-linear (wave-uniform base + 16 B x lane), so the bank-conflict swizzle is applied to
 // the per-lane SOURCE address and again on the fragment read (cdna_hip_programming.md rule 21).
-// Epilogue: accumulators -> per-wave LDS patch (32 x 64 fp32) -> row-major read-back, so that bias / GELU / residual /
-// row mask / 16-bit split run on 4 consecutive columns per lane and every global store instruction writes whole
-// 128 / 256-byte row segments.
+// Epilogue: accumulators -> per-wave LDS patch (32 x 64 fp32, XOR-swizzled) -> row-major read-back, so that bias /
+// GELU / residual / row mask / 16-bit split run on consecutive columns per lane and every global store instruction
+// writes whole 128 / 256-byte row segments.  The patches live in ring slots 2-3; the first two sub-steps of the NEXT
+// tile are DMA-ed into slots 0-1 before the epilogue starts, so the prologue latency of a tile hides under the
+// epilogue of its predecessor.
 // Requires K % (128 / planes) == 0, N % 4 == 0, 16-byte aligned operand rows.
 // ---------------------------------------------------------------------------------------------------------------
 namespace pp {
 constexpr int BM = 256, BN = 256, KS = 32;
 constexpr int SLOT = 32768, W_OFF = 16384, NSLOT = 4;
-constexpr int EPI_LD = 68;                   // floats per staged epilogue row (64 + 4 pad: conflict-free b128 writes)
-constexpr int EPI_WAVE = 32 * EPI_LD * 4;    // bytes of epilogue patch per wave
-constexpr int LDS_BYTES = SLOT * NSLOT;      // 128 KiB
+constexpr int EPI_BASE = 2 * SLOT;        // epilogue patches: slots 2-3
+constexpr int EPI_WAVE = 32 * 64 * 4;     // bytes of epilogue patch per wave: 32 rows x 64 fp32
+constexpr int LDS_BYTES = SLOT * NSLOT;   // 128 KiB
+// float index of 16-byte chunk `chunk` (0..15) of patch row `row`: conflict-free for the fragment writes (8 consecutive
+// rows, one chunk) and for row-major reads whose 16-lane groups stay inside rows of equal row & 7
+__device__ __forceinline__ int es_idx(int row, int chunk) { return row * 64 + ((chunk ^ (row & 7)) << 2); }
 }  // namespace pp
-
-// exact-GELU with erf from Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7) on v_rcp_f32 / v_exp_f32: max abs error of
-// the GELU value 4.7e-7 over [-8, 8] against float64, i.e. inside the error of an fp32 erff-based evaluation (1.2e-6).
-__device__ __forceinline__ float gelu_fast(float x) {
-    const float ax = fabsf(x);
-    const float z = ax * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    const float e = __builtin_amdgcn_exp2f(-(z * z) * 1.4426950408889634f);
-    float q = fmaf(t, 1.061405429f, -1.453152027f);
-    q = fmaf(t, q, 1.421413741f);
-    q = fmaf(t, q, -0.284496736f);
-    q = fmaf(t, q, 0.254829592f);
-    q *= t;
-    const float erf_abs = fmaf(-q, e, 1.0f);
-    return fmaf(0.5f * ax, erf_abs, 0.5f * x);
-}
 
 // In-place MFMA (accumulator tied to its own registers).  With the builtin, hipcc gives every result a fresh register
 // quad; at ~200 live registers the resulting tuple fragmentation spills into the main loop, and a scratch reload's
@@ -321,44 +312,44 @@ __device__ __forceinline__ void mfma16_acc(f32x4& c, bf16x8 a, bf16x8 b) {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 
-// ---- branch-free epilogues for interior wave blocks (all 128 x 64 outputs in range, no row mask) ----
 // stage accumulator fragments 2q, 2q+1 (32 rows x 64 columns) of the wave block into its fp32 LDS patch
 __device__ __forceinline__ void pp_stage_round(float* es, f32x4 (&acc)[4][8], int q, int lane) {
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
-            *(f32x4*)(es + (h * 16 + (lane & 15)) * pp::EPI_LD + ni * 16 + 4 * (lane >> 4)) = acc[ni][2 * q + h];
+            *(f32x4*)(es + pp::es_idx(h * 16 + (lane & 15), ni * 4 + (lane >> 4))) = acc[ni][2 * q + h];
 }
 
+// ---- branch-free epilogues for interior wave blocks (all 128 x 64 outputs in range, no row mask) ----
 // fp32 output (+ bias, + residual): a lane owns 4 consecutive columns; 16 lanes cover a 256-byte row segment.
 // All loads of a 32-row round are issued before the first use, all stores after: no wait inside the round.
 template <bool RES>
 __device__ __forceinline__ void pp_epilogue_f32(const GemmParams& p, f32x4 (&acc)[4][8], float* es, int lane, int mw, int nw) {
-    const int col = (lane & 15) * 4, rsub = lane >> 4;
-    const int n = nw + col;
+    const int ch = lane & 15, rq = (lane >> 4) * 8;  // rows rq + i: every 16-lane group reads rows of equal row & 7
+    const int n = nw + ch * 4;
     const float scale = p.scale;
     float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias) b4 = *(const float4*)(p.bias + n);
-    float* optr = p.out_f32 + (int64_t)(mw + rsub) * p.ldo + n;
-    const float* rptr = RES ? p.residual + (int64_t)(mw + rsub) * p.ldr + n : nullptr;
+    float* optr = p.out_f32 + (int64_t)(mw + rq) * p.ldo + n;
+    const float* rptr = RES ? p.residual + (int64_t)(mw + rq) * p.ldr + n : nullptr;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         float4 r[8];
         if (RES) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) r[i] = *(const float4*)(rptr + (int64_t)(q * 32 + i * 4) * p.ldr);
+            for (int i = 0; i < 8; ++i) r[i] = *(const float4*)(rptr + (int64_t)(q * 32 + i) * p.ldr);
         }
         pp_stage_round(es, acc, q, lane);
         f32x4 c[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) c[i] = *(const f32x4*)(es + (i * 4 + rsub) * pp::EPI_LD + col);
+        for (int i = 0; i < 8; ++i) c[i] = *(const f32x4*)(es + pp::es_idx(rq + i, ch));
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             float4 v = make_float4(fmaf(c[i][0], scale, b4.x), fmaf(c[i][1], scale, b4.y), fmaf(c[i][2], scale, b4.z),
                                    fmaf(c[i][3], scale, b4.w));
             if (RES) { v.x += r[i].x; v.y += r[i].y; v.z += r[i].z; v.w += r[i].w; }
-            *(float4*)(optr + (int64_t)(q * 32 + i * 4) * p.ldo) = v;
+            *(float4*)(optr + (int64_t)(q * 32 + i) * p.ldo) = v;
         }
     }
 }
@@ -368,8 +359,8 @@ __device__ __forceinline__ void pp_epilogue_f32(const GemmParams& p, f32x4 (&acc
 template <typename T, int NT, bool ACT, bool QK>
 __device__ __forceinline__ void pp_epilogue_p16(const GemmParams& p, f32x4 (&acc)[4][8], float* es, int lane, int mw, int nw) {
     typedef typename Vec8<T>::type V8;
-    const int col = (lane & 7) * 8, rs = lane >> 3;
-    const int n = nw + col;
+    const int c8 = lane & 7, rs = lane >> 3;  // rows rs + 8i
+    const int n = nw + c8 * 8;
     const float scale = p.scale;
     float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
     if (p.bias) { b0 = *(const float4*)(p.bias + n); b1 = *(const float4*)(p.bias + n + 4); }
@@ -397,8 +388,8 @@ __device__ __forceinline__ void pp_epilogue_p16(const GemmParams& p, f32x4 (&acc
         f32x4 c[4][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            c[i][0] = *(const f32x4*)(es + (i * 8 + rs) * pp::EPI_LD + col);
-            c[i][1] = *(const f32x4*)(es + (i * 8 + rs) * pp::EPI_LD + col + 4);
+            c[i][0] = *(const f32x4*)(es + pp::es_idx(i * 8 + rs, 2 * c8));
+            c[i][1] = *(const f32x4*)(es + pp::es_idx(i * 8 + rs, 2 * c8 + 1));
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -430,216 +421,17 @@ __device__ __forceinline__ void pp_epilogue_p16(const GemmParams& p, f32x4 (&acc
     }
 }
 
+// edge blocks (M / N tails), row masks, combined fp32 + plane outputs: every feature, runtime flags
 template <typename T, int NT>
-__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
-    typedef typename Vec8<T>::type V8;
+__device__ __forceinline__ void pp_epilogue_generic(const GemmParams& p, f32x4 (&acc)[4][8], float* es, int lane, int mw, int nw) {
     typedef typename Vec4<T>::type V4;
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-    const int tid = threadIdx.x;
-    int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2, wc = wave & 3;
-
-    // XCD-aware tile order (see gemm_kernel): 32 co-resident tiles of one XCD = 8 M-tiles x 4 N-tiles.
-    int tile_m, tile_n;
-    {
-        const int ntn = gridDim.x, ntm = gridDim.y;
-        const int total = ntn * ntm;
-        const int lin = blockIdx.x + blockIdx.y * ntn;
-        const int xcd = lin & 7, q = total >> 3, r = total & 7;
-        const int i = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
-        constexpr int GM = 8;
-        const int per_group = GM * ntn;
-        const int group = i / per_group;
-        const int first_m = group * GM;
-        const int gsize = ntm - first_m < GM ? ntm - first_m : GM;
-        const int in_group = i - group * per_group;
-        tile_m = first_m + in_group % gsize;
-        tile_n = in_group / gsize;
-    }
-    const int m0 = tile_m * pp::BM, n0 = tile_n * pp::BN;
-
-    // ---- DMA sources: this wave fills pieces 2*wave, 2*wave+1 (16 rows x 64 B each) of the A part and of the W part.
-    // Addresses are (wave-uniform tile base) + (32-bit per-lane byte offset): SGPR base + VGPR offset addressing keeps
-    // the per-lane state at four registers.
-    const int m0c = m0 < p.M ? m0 : p.M - 1, n0c = n0 < p.N ? n0 : p.N - 1;
-    const int64_t b0 = m0c / p.rows_per_batch;
-    const int64_t a_tile = b0 * p.a_batch_stride + (m0c - b0 * p.rows_per_batch) * p.lda;  // element offset of row m0
-    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.A + a_tile), 0, -1, 0x00020000);
-    const __amdgpu_buffer_rsrc_t w_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.W + (int64_t)n0c * p.ldw), 0, -1, 0x00020000);
-    uint32_t a_off[2], w_off[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = (wave * 2 + j) * 16 + (lane >> 2);
-        const int lc = (lane & 3) ^ ((row >> 2) & 2);  // logical 16-byte chunk stored at physical chunk lane & 3
-        int r = m0 + row;
-        r = r < p.M ? r : p.M - 1;
-        const int64_t b = r / p.rows_per_batch;
-        const int64_t t = r - b * p.rows_per_batch;
-        a_off[j] = (uint32_t)((b * p.a_batch_stride + t * p.lda - a_tile + lc * 8) * 2);
-        int rn = n0 + row;
-        rn = rn < p.N ? rn : p.N - 1;
-        w_off[j] = (uint32_t)(((int64_t)(rn - n0c) * p.ldw + lc * 8) * 2);
-    }
-    const uint32_t a_plane_b = (uint32_t)(p.a_plane * 2), w_plane_b = (uint32_t)(p.w_plane * 2);
-
-    // ---- fragment read offsets (bytes inside a slot) ----
-    const int rd_chunk = ((lane >> 4) ^ ((lane >> 2) & 2)) << 4;
-    const int a_rd = (grp * 128 + (lane & 15)) * 64 + rd_chunk;
-    const int w_rd = pp::W_OFF + (wc * 64 + (lane & 15)) * 64 + rd_chunk;
-
-    f32x4 acc[4][8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    V8 fa[NT][8], fw[NT][4];
-
-    // DMA of the A part and / or W part of (plane, k-offset) into a ring slot
-    auto stage = [&](int slot, int plane, bool do_a, bool do_w, int koff) {
-        unsigned char* dst = smem + slot * pp::SLOT + wave * 2048;
-        if (do_a) {
-            const uint32_t so = plane * a_plane_b + (uint32_t)koff * 2;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_ptr_t)(dst + j * 1024), 16, a_off[j], so, 0, 0);
-        }
-        if (do_w) {
-            const uint32_t so = plane * w_plane_b + (uint32_t)koff * 2;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(dst + pp::W_OFF + j * 1024), 16, w_off[j], so, 0, 0);
-        }
-    };
-
-    // One LOAD segment + one MFMA segment.  Compile-time code: read slot RS (A and / or W fragments into plane DPL of
-    // the fragment registers), product PROD (0: W.A on plane 0, 1: lo(W).hi(A), 2: hi(W).lo(A)), and the DMA that
-    // refills, three segments ahead, the same parts of slot SS from plane SPL.
-    auto segment = [&](auto code, bool stage_ok, int stage_koff) {
-        constexpr int C = decltype(code)::value;
-        constexpr int RS = C & 3, RA = (C >> 2) & 1, RW = (C >> 3) & 1, DPL = (C >> 4) & 1, PROD = (C >> 5) & 3,
-                      SS = (C >> 7) & 3, SPL = (C >> 9) & 1;
-        // ---------------- LOAD segment ----------------
-        const unsigned char* s = smem + RS * pp::SLOT;
-        if (RA) {
-#pragma unroll
-            for (int mi = 0; mi < 8; ++mi) fa[DPL][mi] = *(const V8*)(s + a_rd + mi * 1024);
-        }
-        if (RW) {
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) fw[DPL][ni] = *(const V8*)(s + w_rd + ni * 1024);
-        }
-        if (stage_ok) stage(SS, SPL, RA, RW, stage_koff);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        // ---------------- MFMA segment ----------------
-        __builtin_amdgcn_s_setprio(1);
-        constexpr int PW = PROD == 1 ? NT - 1 : 0, PA = PROD == 2 ? NT - 1 : 0;
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-            for (int mi = 0; mi < 8; ++mi) mfma16_acc(acc[ni][mi], fw[PW][ni], fa[PA][mi]);
-        __builtin_amdgcn_s_setprio(0);
-        // retire every DMA except the one issued in this segment (same parts => same piece count)
-        if (stage_ok) {
-            if (RA && RW) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    };
-#define PP_CODE(RS, RA, RW, DPL, PROD, SS, SPL) \
-    std::integral_constant<int, (RS) | ((RA) << 2) | ((RW) << 3) | ((DPL) << 4) | ((PROD) << 5) | ((SS) << 7) | ((SPL) << 9)> {}
-
-    if constexpr (NT == 1) {
-        // segments = 32-deep K slices; slice u lives in slot u % 4
-        const int nseg = p.K / pp::KS;
-        stage(0, 0, true, true, 0);
-        stage(1, 0, true, true, pp::KS);
-        stage(2, 0, true, true, 2 * pp::KS);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // slices 0 and 1 have landed
-        __builtin_amdgcn_s_barrier();
-        if (grp == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind group 0
-        for (int u = 0; u < nseg; u += 4) {
-            segment(PP_CODE(0, 1, 1, 0, 0, 3, 0), u + 3 < nseg, (u + 3) * pp::KS);
-            segment(PP_CODE(1, 1, 1, 0, 0, 0, 0), u + 4 < nseg, (u + 4) * pp::KS);
-            segment(PP_CODE(2, 1, 1, 0, 0, 1, 0), u + 5 < nseg, (u + 5) * pp::KS);
-            segment(PP_CODE(3, 1, 1, 0, 0, 2, 0), u + 6 < nseg, (u + 6) * pp::KS);
-        }
-    } else {
-        // three segments per 32-deep K slice k: H (hi planes of A and W: hi.hi), LW (lo plane of W: lo(W).hi(A)),
-        // LA (lo plane of A: hi(W).lo(A)); hi planes of slice k in slot 2*(k%2), lo planes in slot 2*(k%2)+1.
-        const int nk = p.K / pp::KS;
-        stage(0, 0, true, true, 0);
-        stage(1, 1, false, true, 0);
-        stage(1, 1, true, false, 0);
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // H(0) and LW(0) have landed
-        __builtin_amdgcn_s_barrier();
-        if (grp == 1) __builtin_amdgcn_s_barrier();
-        for (int k = 0; k < nk; k += 2) {
-            const bool ok1 = k + 1 < nk, ok2 = k + 2 < nk;
-            segment(PP_CODE(0, 1, 1, 0, 0, 2, 0), ok1, (k + 1) * pp::KS);
-            segment(PP_CODE(1, 0, 1, 1, 1, 3, 1), ok1, (k + 1) * pp::KS);
-            segment(PP_CODE(1, 1, 0, 1, 2, 3, 1), ok1, (k + 1) * pp::KS);
-            segment(PP_CODE(2, 1, 1, 0, 0, 0, 0), ok2, (k + 2) * pp::KS);
-            segment(PP_CODE(3, 0, 1, 1, 1, 1, 1), ok2, (k + 2) * pp::KS);
-            segment(PP_CODE(3, 1, 0, 1, 2, 1, 1), ok2, (k + 2) * pp::KS);
-        }
-    }
-#undef PP_CODE
-    if (grp == 0) __builtin_amdgcn_s_barrier();  // realign the groups: every LDS read and DMA of the ring is complete
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // MFMA results -> VALU / LDS readers (the MFMAs are inline asm)
-
-#ifdef AMX_ABLATE_NO_EPI
-    if (p.M > 0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(acc[i][j]));
-        return;
-    }
-#endif
-
-    // ---------------------------------------- epilogue ----------------------------------------
-    // make the lane id opaque so that no epilogue address arithmetic is hoisted above the main loop (register pressure)
-    asm volatile("" : "+v"(lane));
-    const int mw = m0 + grp * 128, nw = n0 + wc * 64;
-    if (nw >= p.N || mw >= p.M) return;
     const int D = p.H * p.dh;
     const float scale = p.scale;
-
-    float* es = (float*)(smem + wave * pp::EPI_WAVE);
-    if (mw + 128 <= p.M && nw + 64 <= p.N && !p.row_len && p.vec_ok) {
-        // interior block: branch-free epilogues
-        if (p.mode == 1) {
-            if (p.T >= 8 && p.dh % 8 == 0 && p.qk_plane % 8 == 0 && !(((uintptr_t)p.q | (uintptr_t)p.k | (uintptr_t)p.v) & 15)) {
-                pp_epilogue_p16<T, NT, false, true>(p, acc, es, lane, mw, nw);
-                return;
-            }
-        } else if (p.out_f32 && !p.out_p && p.act == 0) {
-            if (p.residual) pp_epilogue_f32<true>(p, acc, es, lane, mw, nw);
-            else pp_epilogue_f32<false>(p, acc, es, lane, mw, nw);
-            return;
-        } else if (p.out_p && !p.out_f32 && !p.residual && p.ldp % 8 == 0 && p.out_plane % 8 == 0 && !((uintptr_t)p.out_p & 15)) {
-            if (p.act == 1) pp_epilogue_p16<T, NT, true, false>(p, acc, es, lane, mw, nw);
-            else pp_epilogue_p16<T, NT, false, false>(p, acc, es, lane, mw, nw);
-            return;
-        }
-    }
-    const int col = (lane & 15) * 4, rsub = lane >> 4;
-    const int n = nw + col;
+    const int ch = lane & 15, rq = (lane >> 4) * 8;
+    const int n = nw + ch * 4;
     const bool n_ok = n < p.N;  // N % 4 == 0: all four columns or none
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias && n_ok) bias4 = *(const float4*)(p.bias + n);
-    // per-lane column decomposition of the Q / K scatter
     int64_t qk_col = 0;
     T* qk_base = nullptr;
     if (p.mode == 1 && n_ok) {
@@ -649,30 +441,22 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         qk_base = (T*)(which == 0 ? p.q : (which == 1 ? p.k : p.v));
         qk_col = (int64_t)hh * p.Tp * p.dh + d;
     }
-    // (batch, position) of the lane's first row; rows advance by 4
     const bool need_bt = p.row_len || p.mode == 1;
     const int rt = p.mode == 1 ? p.T : p.rows_T;
-    int b = 0, t = 0;
-    if (need_bt) {
-        const int mfirst = mw + rsub;
-        b = mfirst / rt;
-        t = mfirst - b * rt;
-    }
-
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        // accumulator fragments 2q, 2q+1 (32 rows) -> LDS patch, fp32, row-major [32][64 (+4)]
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-                *(f32x4*)(es + (h * 16 + (lane & 15)) * pp::EPI_LD + ni * 16 + 4 * (lane >> 4)) = acc[ni][2 * q + h];
+        pp_stage_round(es, acc, q, lane);
         // LDS operations of one wave complete in order: the reads below see the writes above
+        int b = 0, t = 0;
+        if (need_bt) {
+            const int mfirst = mw + q * 32 + rq;
+            b = mfirst / rt;
+            t = mfirst - b * rt;
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int rl = i * 4 + rsub;
-            const int m = mw + q * 32 + rl;
-            const f32x4 c = *(const f32x4*)(es + rl * pp::EPI_LD + col);
+            const int m = mw + q * 32 + rq + i;
+            const f32x4 c = *(const f32x4*)(es + pp::es_idx(rq + i, ch));
             if (m < p.M && n_ok) {
                 float v[4] = {fmaf(c[0], scale, bias4.x), fmaf(c[1], scale, bias4.y), fmaf(c[2], scale, bias4.z),
                               fmaf(c[3], scale, bias4.w)};
@@ -713,11 +497,297 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
                 }
             }
             if (need_bt) {
-                t += 4;
-                while (t >= rt) { t -= rt; ++b; }
+                t += 1;
+                if (t >= rt) { t = 0; ++b; }
             }
         }
     }
+}
+
+template <typename T, int NT>
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
+    typedef typename Vec8<T>::type V8;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wc = wave & 3;
+    const int ntn = (p.N + pp::BN - 1) / pp::BN, ntm = (p.M + pp::BM - 1) / pp::BM;
+    const int total = ntn * ntm;
+
+    // ---- fragment read offsets (bytes inside a slot) ----
+    const int rd_chunk = ((lane >> 4) ^ ((lane >> 2) & 2)) << 4;
+    const int a_rd = (grp * 128 + (lane & 15)) * 64 + rd_chunk;
+    const int w_rd = pp::W_OFF + (wc * 64 + (lane & 15)) * 64 + rd_chunk;
+    const uint32_t a_plane_b = (uint32_t)(p.a_plane * 2), w_plane_b = (uint32_t)(p.w_plane * 2);
+
+    // ---- per-tile DMA state: this wave fills pieces 2*wave, 2*wave+1 (16 rows x 64 B each) of the A part and of the
+    // W part of a slot; addresses are (wave-uniform tile base in an SGPR buffer descriptor) + (32-bit per-lane offset)
+    int m0 = 0, n0 = 0;
+    __amdgpu_buffer_rsrc_t a_rsrc, w_rsrc;
+    uint32_t a_off[2], w_off[2];
+    auto setup_tile = [&](int i) {
+        // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (private 4 MiB L2 each), so the tile
+        // sequence numbers that share an XCD (equal i % 8) are given one contiguous chunk of a grouped tile sequence in
+        // which the 32 co-resident tiles of an XCD form an 8 (M) x 4 (N) rectangle.  Pure speed: any placement gives
+        // the same results.
+        const int xcd = i & 7, q = total >> 3, r = total & 7;
+        const int j = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (i >> 3);  // bijective remap
+        constexpr int GM = 8;
+        const int per_group = GM * ntn;
+        const int group = j / per_group;
+        const int first_m = group * GM;
+        const int gsize = ntm - first_m < GM ? ntm - first_m : GM;
+        const int in_group = j - group * per_group;
+        m0 = (first_m + in_group % gsize) * pp::BM;
+        n0 = (in_group / gsize) * pp::BN;
+        const int m0c = m0 < p.M ? m0 : p.M - 1, n0c = n0 < p.N ? n0 : p.N - 1;
+        const int64_t b0 = m0c / p.rows_per_batch;
+        const int64_t a_tile = b0 * p.a_batch_stride + (m0c - b0 * p.rows_per_batch) * p.lda;  // element offset of row m0
+        a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.A + a_tile), 0, -1, 0x00020000);
+        w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.W + (int64_t)n0c * p.ldw), 0, -1, 0x00020000);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int row = (wave * 2 + jj) * 16 + ((tid & 63) >> 2);
+            const int lc = (tid & 3) ^ ((row >> 2) & 2);  // logical 16-byte chunk stored at physical chunk lane & 3
+            int rr = m0 + row;
+            rr = rr < p.M ? rr : p.M - 1;
+            const int64_t b = rr / p.rows_per_batch;
+            const int64_t t = rr - b * p.rows_per_batch;
+            a_off[jj] = (uint32_t)((b * p.a_batch_stride + t * p.lda - a_tile + lc * 8) * 2);
+            int rn = n0 + row;
+            rn = rn < p.N ? rn : p.N - 1;
+            w_off[jj] = (uint32_t)(((int64_t)(rn - n0c) * p.ldw + lc * 8) * 2);
+        }
+    };
+
+    f32x4 acc[4][8];
+    V8 fa[NT][8], fw[NT][4];
+
+    // DMA of the A part and / or W part of (plane, k-offset) into a ring slot
+    auto stage = [&](int slot, int plane, bool do_a, bool do_w, int koff) {
+        unsigned char* dst = smem + slot * pp::SLOT + wave * 2048;
+        if (do_a) {
+            const uint32_t so = plane * a_plane_b + (uint32_t)koff * 2;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_ptr_t)(dst + j * 1024), 16, a_off[j], so, 0, 0);
+        }
+        if (do_w) {
+            const uint32_t so = plane * w_plane_b + (uint32_t)koff * 2;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(dst + pp::W_OFF + j * 1024), 16, w_off[j], so, 0, 0);
+        }
+    };
+    // the first two sub-steps of a tile (slots 0 and 1; none of them touches the epilogue patches in slots 2-3)
+    auto stage_head = [&]() {
+        if constexpr (NT == 1) {
+            stage(0, 0, true, true, 0);
+            stage(1, 0, true, true, pp::KS);
+        } else {
+            stage(0, 0, true, true, 0);   // H(0)
+            stage(1, 1, false, true, 0);  // LW(0)
+        }
+    };
+
+    // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate)
+    auto wait_dma = [](int keep) {
+        if (keep >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (keep >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (keep >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (keep >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+#ifdef AMX_PP_STAMP
+    // developer diagnostic (tools/gemm_bench.hip, -DAMX_PP_STAMP): cycles per phase of the LOAD / MFMA segments, summed
+    // over the main loops in scalar registers; lane 0 of waves 0 and 4 writes them to p.stamps
+    unsigned long long st_load = 0, st_bar1 = 0, st_mfma = 0, st_vm = 0, st_bar2 = 0, st_prev = 0, st_begin_rt = 0, st_loop = 0;
+    auto stamp = []() -> unsigned long long {
+        unsigned long long t;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+        return t;
+    };
+    {
+        unsigned long long t;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        st_begin_rt = t;
+    }
+    const unsigned long long st_begin = stamp();
+#endif
+    // One LOAD segment + one MFMA segment.  Compile-time code: read slot RS (A and / or W fragments into plane DPL of
+    // the fragment registers), product PROD (0: W.A on plane 0, 1: lo(W).hi(A), 2: hi(W).lo(A)), the DMA that refills,
+    // three segments ahead, the same parts of slot SS from plane SPL, and CNT2 = DMA pieces of the segment two ahead.
+    auto segment = [&](auto code, bool stage_ok, int stage_koff, bool next2_ok) {
+        constexpr int C = decltype(code)::value;
+        constexpr int RS = C & 3, RA = (C >> 2) & 1, RW = (C >> 3) & 1, DPL = (C >> 4) & 1, PROD = (C >> 5) & 3,
+                      SS = (C >> 7) & 3, SPL = (C >> 9) & 1, CNT2 = (C >> 10) & 7;
+        constexpr int CNT3 = 2 * (RA + RW);
+        // DMA pieces that may stay in flight past this segment's wait: those of sub-steps u+2 and u+3
+        const int keep = (stage_ok ? CNT3 : 0) + (next2_ok ? CNT2 : 0);
+        // ---------------- LOAD segment ----------------
+#ifdef AMX_PP_STAMP
+        const unsigned long long t0 = stamp();
+        if (st_prev) st_bar2 += t0 - st_prev;
+#endif
+        const unsigned char* s = smem + RS * pp::SLOT;
+        if (RA) {
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) fa[DPL][mi] = *(const V8*)(s + a_rd + mi * 1024);
+        }
+        if (RW) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) fw[DPL][ni] = *(const V8*)(s + w_rd + ni * 1024);
+        }
+        if (stage_ok) stage(SS, SPL, RA, RW, stage_koff);
+        if (grp == 1) wait_dma(keep);  // group 1 publishes sub-step u+1 with the barrier that ends its LOAD segment
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef AMX_PP_STAMP
+        const unsigned long long t1 = stamp();
+        st_load += t1 - t0;
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef AMX_PP_STAMP
+        const unsigned long long t2 = stamp();
+        st_bar1 += t2 - t1;
+#endif
+        // ---------------- MFMA segment ----------------
+        __builtin_amdgcn_s_setprio(1);
+        constexpr int PW = PROD == 1 ? NT - 1 : 0, PA = PROD == 2 ? NT - 1 : 0;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) mfma16_acc(acc[ni][mi], fw[PW][ni], fa[PA][mi]);
+        __builtin_amdgcn_s_setprio(0);
+#ifdef AMX_PP_STAMP
+        const unsigned long long t3 = stamp();
+        st_mfma += t3 - t2;
+#endif
+        if (grp == 0) wait_dma(keep);  // group 0 publishes sub-step u+1 with the barrier that ends its MFMA segment
+#ifdef AMX_PP_STAMP
+        const unsigned long long t4 = stamp();
+        st_vm += t4 - t3;
+        st_prev = t4;
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#define PP_CODE(RS, RA, RW, DPL, PROD, SS, SPL, CNT2) \
+    std::integral_constant<int, (RS) | ((RA) << 2) | ((RW) << 3) | ((DPL) << 4) | ((PROD) << 5) | ((SS) << 7) | ((SPL) << 9) | ((CNT2) << 10)> {}
+
+    int it = blockIdx.x;
+    setup_tile(it);
+    stage_head();
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef AMX_PP_STAMP
+        const unsigned long long st_l0 = stamp();
+        st_prev = 0;
+#endif
+        if constexpr (NT == 1) {
+            // segments = 32-deep K slices; slice u lives in slot u % 4
+            const int nseg = p.K / pp::KS;
+            stage(2, 0, true, true, 2 * pp::KS);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // slice 0 has landed
+            __builtin_amdgcn_s_barrier();
+            if (grp == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind group 0
+            for (int u = 0; u < nseg; u += 4) {
+                segment(PP_CODE(0, 1, 1, 0, 0, 3, 0, 4), u + 3 < nseg, (u + 3) * pp::KS, u + 2 < nseg);
+                segment(PP_CODE(1, 1, 1, 0, 0, 0, 0, 4), u + 4 < nseg, (u + 4) * pp::KS, u + 3 < nseg);
+                segment(PP_CODE(2, 1, 1, 0, 0, 1, 0, 4), u + 5 < nseg, (u + 5) * pp::KS, u + 4 < nseg);
+                segment(PP_CODE(3, 1, 1, 0, 0, 2, 0, 4), u + 6 < nseg, (u + 6) * pp::KS, u + 5 < nseg);
+            }
+        } else {
+            // hi planes of slice k in slot 2*(k%2), lo planes in slot 2*(k%2)+1
+            const int nk = p.K / pp::KS;
+            stage(1, 1, true, false, 0);                      // LA(0)
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // H(0) has landed
+            __builtin_amdgcn_s_barrier();
+            if (grp == 1) __builtin_amdgcn_s_barrier();
+            for (int k = 0; k < nk; k += 2) {  // nk is even
+                const bool ok2 = k + 2 < nk;
+                segment(PP_CODE(0, 1, 1, 0, 0, 2, 0, 2), true, (k + 1) * pp::KS, true);
+                segment(PP_CODE(1, 0, 1, 1, 1, 3, 1, 4), true, (k + 1) * pp::KS, true);
+                segment(PP_CODE(1, 1, 0, 1, 2, 3, 1, 2), true, (k + 1) * pp::KS, true);
+                segment(PP_CODE(2, 1, 1, 0, 0, 0, 0, 2), ok2, (k + 2) * pp::KS, true);
+                segment(PP_CODE(3, 0, 1, 1, 1, 1, 1, 4), ok2, (k + 2) * pp::KS, ok2);
+                segment(PP_CODE(3, 1, 0, 1, 2, 1, 1, 2), ok2, (k + 2) * pp::KS, ok2);
+            }
+        }
+        if (grp == 0) __builtin_amdgcn_s_barrier();  // realign the groups: every LDS read and DMA of the ring is complete
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // MFMA results -> VALU / LDS readers (the MFMAs are inline asm)
+#ifdef AMX_PP_STAMP
+        st_loop += stamp() - st_l0;
+#endif
+
+        // ---- next tile: set up its DMA state and start its first two sub-steps under this tile's epilogue ----
+        const int mw = m0 + grp * 128, nw = n0 + wc * 64;
+        const int next = it + gridDim.x;
+        const bool has_next = next < total;
+        if (has_next) {
+            setup_tile(next);
+            stage_head();
+        }
+
+        // ---------------------------------------- epilogue ----------------------------------------
+#ifndef AMX_ABLATE_NO_EPI
+        // make the lane id opaque so that no epilogue address arithmetic is hoisted above the main loop (register pressure)
+        asm volatile("" : "+v"(lane));
+        if (nw < p.N && mw < p.M) {
+            float* es = (float*)(smem + pp::EPI_BASE + wave * pp::EPI_WAVE);
+            bool done = false;
+            if (mw + 128 <= p.M && nw + 64 <= p.N && !p.row_len && p.vec_ok) {
+                // interior block: branch-free epilogues
+                if (p.mode == 1) {
+                    if (p.T >= 8 && p.dh % 8 == 0 && p.qk_plane % 8 == 0 && !(((uintptr_t)p.q | (uintptr_t)p.k | (uintptr_t)p.v) & 15)) {
+                        pp_epilogue_p16<T, NT, false, true>(p, acc, es, lane, mw, nw);
+                        done = true;
+                    }
+                } else if (p.out_f32 && !p.out_p && p.act == 0) {
+                    if (p.residual) pp_epilogue_f32<true>(p, acc, es, lane, mw, nw);
+                    else pp_epilogue_f32<false>(p, acc, es, lane, mw, nw);
+                    done = true;
+                } else if (p.out_p && !p.out_f32 && !p.residual && p.ldp % 8 == 0 && p.out_plane % 8 == 0 && !((uintptr_t)p.out_p & 15)) {
+                    if (p.act == 1) pp_epilogue_p16<T, NT, true, false>(p, acc, es, lane, mw, nw);
+                    else pp_epilogue_p16<T, NT, false, false>(p, acc, es, lane, mw, nw);
+                    done = true;
+                }
+            }
+            if (!done) pp_epilogue_generic<T, NT>(p, acc, es, lane, mw, nw);
+        }
+#else
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(acc[i][j]));
+#endif
+        if (!has_next) break;
+        it = next;
+        // every wave is done with its patch (its LDS reads have returned) before slot 2 is refilled
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+#undef PP_CODE
+#ifdef AMX_PP_STAMP
+    if (p.stamps && (wave == 0 || wave == 4) && (tid & 63) == 0) {
+        const unsigned long long st_end = stamp();
+        unsigned long long rt;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt)::"memory");
+        unsigned long long* o = p.stamps + ((int64_t)blockIdx.x * 2 + (wave >> 2)) * 10;
+        o[0] = st_load; o[1] = st_bar1; o[2] = st_mfma; o[3] = st_vm; o[4] = st_bar2; o[5] = st_loop;
+        o[6] = rt - st_begin_rt; o[7] = 1; o[8] = st_end - st_begin; o[9] = (unsigned long long)((total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x);
+    }
+#endif
 }
 
 bool pp_eligible(int NT, const GemmParams& p) {
@@ -755,7 +825,17 @@ bool launch_gemm_pp(const GemmParams& p, hipStream_t stream) {
         (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, pp::LDS_BYTES);
         attr_set = true;
     }
-    dim3 grid((p.N + pp::BN - 1) / pp::BN, (p.M + pp::BM - 1) / pp::BM, 1);
+    const int tiles = ((p.N + pp::BN - 1) / pp::BN) * ((p.M + pp::BM - 1) / pp::BM);
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+        cus -= cus % 8;  // the tile order assumes sequence numbers i and i + grid share an XCD
+        if (cus < 8) cus = 8;
+    }
+    dim3 grid(tiles < cus ? tiles : cus, 1, 1);  // persistent: one 128-KiB-LDS workgroup per CU
     hipLaunchKernelGGL((gemm_pp_kernel<T, NT>), grid, dim3(512), pp::LDS_BYTES, stream, p);
     return true;
 }

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ au
         T hi[CPL], lo[CPL];
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
-            float y = gelu_erf((acc[i] - mu) * rs * gr[i] + be[i]);
+            float y = gelu_fast((acc[i] - mu) * rs * gr[i] + be[i]);
             split16<T, NT>(y, hi[i], lo[i]);
         }
         if (active) {
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
                 y.y = (v[i].y - mu) * rs * gg.y + bb.y;
                 y.z = (v[i].z - mu) * rs * gg.z + bb.z;
                 y.w = (v[i].w - mu) * rs * gg.w + bb.w;
-                if (act) { y.x = gelu_erf(y.x); y.y = gelu_erf(y.y); y.z = gelu_erf(y.z); y.w = gelu_erf(y.w); }
+                if (act) { y.x = gelu_fast(y.x); y.y = gelu_fast(y.y); y.z = gelu_fast(y.z); y.w = gelu_fast(y.w); }
                 v[i] = y;
             }
         }

@@ -182,7 +182,56 @@ static double run_case(int prec, const Case& c, bool timing_only, double* us_pp,
     return worst;
 }
 
+#ifdef AMX_PP_STAMP
+// phase anatomy of the ping-pong main loop: per-segment cycles of the LOAD / MFMA phases and the in-kernel clock
+static void run_stamp(int prec, int M, int N, int K, const char* name) {
+    const int NT = prec_planes(prec);
+    size_t a_el = (size_t)M * K, w_el = (size_t)N * K, o_el = (size_t)M * N;
+    void *A, *W; float *bias, *outf;
+    CK(hipMalloc(&A, a_el * 2 * NT)); CK(hipMalloc(&W, w_el * 2 * NT)); CK(hipMalloc(&bias, N * 4)); CK(hipMalloc(&outf, o_el * 4));
+    fill16(A, a_el, 1, prec, false); fill16(W, w_el, 2, prec, false);
+    if (NT > 1) { fill16((char*)A + a_el * 2, a_el, 3, prec, true); fill16((char*)W + w_el * 2, w_el, 4, prec, true); }
+    fill32(bias, N, 5, 0.5f);
+    const int nblk = 256;  // persistent grid: at most one workgroup per CU
+    unsigned long long* st; CK(hipMalloc(&st, (size_t)nblk * 20 * 8)); CK(hipMemset(st, 0, (size_t)nblk * 20 * 8));
+    GemmParams g{};
+    g.A = A; g.a_plane = a_el; g.lda = K; g.rows_per_batch = M; g.W = W; g.w_plane = w_el; g.ldw = K; g.M = M; g.N = N; g.K = K;
+    g.scale = 1.f; g.bias = bias; g.out_f32 = outf; g.ldo = N; g.stamps = st;
+    for (int i = 0; i < 30; ++i) launch_gemm(prec, g, 0);  // warm: let the clock settle under load
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> h((size_t)nblk * 20);
+    CK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
+    const int nseg = (NT == 1 ? 1 : 3) * (K / 32);
+    for (int grp = 0; grp < 2; ++grp) {
+        double s[9] = {0}; int cnt = 0; double tiles = 0;
+        for (int b = 0; b < nblk; ++b) {
+            const unsigned long long* o = &h[((size_t)b * 2 + grp) * 10];
+            if (!o[7]) continue;
+            for (int i = 0; i < 9; ++i) s[i] += (double)o[i];
+            tiles += (double)o[9];
+            ++cnt;
+        }
+        if (!cnt) continue;
+        const double segs = tiles * nseg;  // segments summed over all sampled workgroups
+        printf("STAMP prec=%d %-10s grp%d  per segment: load %.0f  bar1 %.0f  mfma %.0f  vmwait %.0f  bar2 %.0f | per tile: main loop %.0f cyc of %.0f total (%.1f tiles/WG)  clock %.0f MHz\n",
+               prec, name, grp, s[0] / segs, s[1] / segs, s[2] / segs, s[3] / segs, s[4] / segs, s[5] / tiles, s[8] / tiles, tiles / cnt,
+               s[8] / (s[6] / 100.0));
+    }
+    CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(bias)); CK(hipFree(outf)); CK(hipFree(st));
+}
+#endif
+
 int main(int argc, char** argv) {
+#ifdef AMX_PP_STAMP
+    if (argc > 1 && !strcmp(argv[1], "stamp")) {
+        int precs[] = {PREC_F16X3, PREC_BF16, PREC_F16};
+        for (int prec : precs) {
+            run_stamp(prec, 15968, 4096, 1024, "ffn1-like");
+            run_stamp(prec, 15968, 1024, 4096, "ffn2-like");
+        }
+        return 0;
+    }
+#endif
     const bool check = argc < 2 || !strcmp(argv[1], "check");
     const bool timing = argc < 2 || !strcmp(argv[1], "time");
     if (check) {
