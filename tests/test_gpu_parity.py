@@ -247,6 +247,32 @@ def test_restore_from_checkpoint_schema(amd, tmp_path):
     est.close()
 
 
+def test_xlsr_shape_large_batch_against_oracle(amd):
+    """XLS-R-300m shape with N * T >= 1024 rows, so that every large product (conv layers, feature projection, QKV /
+    out-proj / FFN, phoneme head) runs on the 256 x 256 ping-pong GEMM and the attention sees ragged key lengths --
+    checked against the CPU oracle on fresh seeded inputs (8 ragged 3 s utterances)."""
+    from oracle import allophant_oracle as O
+
+    spec = S.multitask_spec(S.xlsr_300m_encoder(), allophone_layer=True)
+    spec["shared_phones"] = 80
+    state = synthetic.make_state_dict(spec, seed=0)
+    tfi = synthetic.make_inventory(spec, 27, seed=3)
+    audio, lengths = synthetic.make_audio(8, 48000, seed=4321, ragged=True)
+    est = amd.Estimator(spec, state, "cuda:0", "f16x3")
+    pred = est.predict(amd.Batch(audio.cuda(), lengths, torch.zeros(8, dtype=torch.long)), tfi)
+    assert pred.outputs["phoneme"].shape[0] * 8 >= 1024
+    ref, ref_len = O.predict(audio, lengths, state, spec, tfi, synthetic.category_offsets(spec))
+    assert list(pred.outputs) == list(ref) and torch.equal(pred.lengths.cpu(), ref_len)
+    worst = max(max_abs_valid_tm(pred.outputs[k].cpu(), ref[k], ref_len) for k in ref)
+    assert worst < GATE, worst
+    decoded = est.greedy_decode(pred)
+    for k in ("phoneme", "syllabic", "click"):
+        hyps = O.greedy_ctc(ref[k].transpose(0, 1).contiguous(), ref_len)
+        for i, (tokens, timesteps, _score) in enumerate(hyps):
+            assert torch.equal(decoded[k][i][0].tokens, tokens) and torch.equal(decoded[k][i][0].timesteps, timesteps), (k, i)
+    est.close()
+
+
 def test_full_size_properties(amd):
     """BASELINE config-2 sizes (32 x 10 s, XLS-R shape) are too big for the CPU oracle inside a test, so the full-size
     run is checked through size-independent properties: probabilities normalise, padded frames never leak into valid
