@@ -111,51 +111,67 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ au
     }
     __syncthreads();
     const float invC = 1.0f / (float)C;
-    for (int f = wave; f < C0_FRAMES; f += 4) {
-        const int t = f0 + f;
-        if (t >= T1) break;
-        float acc[CPL];
+    // two frames per wave iteration: the two dependent chains (conv -> mean -> variance -> GELU) interleave
+    constexpr int FPI = 2;
+    for (int f = wave * FPI; f < C0_FRAMES; f += 4 * FPI) {
+        float acc[FPI][CPL];
 #pragma unroll
-        for (int i = 0; i < CPL; ++i) acc[i] = br[i];
+        for (int u = 0; u < FPI; ++u)
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) acc[u][i] = br[i];
 #pragma unroll
         for (int j = 0; j < KW; ++j) {
-            float x = j < k ? win[f * stride + j] : 0.f;
 #pragma unroll
-            for (int i = 0; i < CPL; ++i) acc[i] = fmaf(wr[i][j], x, acc[i]);
+            for (int u = 0; u < FPI; ++u) {
+                const float x = j < k ? win[(f + u) * stride + j] : 0.f;  // f + u < C0_FRAMES: inside the staged window
+#pragma unroll
+                for (int i = 0; i < CPL; ++i) acc[u][i] = fmaf(wr[i][j], x, acc[u][i]);
+            }
         }
-        float s = 0.f;
+        float mu[FPI], rs[FPI];
 #pragma unroll
-        for (int i = 0; i < CPL; ++i) s += (c0 + i < C) ? acc[i] : 0.f;
-        const float mu = wave_sum(s) * invC;
-        float q = 0.f;
+        for (int u = 0; u < FPI; ++u) {
+            float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < CPL; ++i) {
-            float d = acc[i] - mu;
-            q += (c0 + i < C) ? d * d : 0.f;
+            for (int i = 0; i < CPL; ++i) s += (c0 + i < C) ? acc[u][i] : 0.f;
+            mu[u] = wave_sum(s) * invC;
         }
-        const float rs = 1.0f / sqrtf(wave_sum(q) * invC + eps);
-        T hi[CPL], lo[CPL];
 #pragma unroll
-        for (int i = 0; i < CPL; ++i) {
-            float y = gelu_fast((acc[i] - mu) * rs * gr[i] + be[i]);
-            split16<T, NT>(y, hi[i], lo[i]);
+        for (int u = 0; u < FPI; ++u) {
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) {
+                float d = acc[u][i] - mu[u];
+                q += (c0 + i < C) ? d * d : 0.f;
+            }
+            rs[u] = 1.0f / sqrtf(wave_sum(q) * invC + eps);
         }
-        if (active) {
-            T* dst = out + ((int64_t)n * T1 + t) * C + c0;
-            if constexpr (CPL == 8) {
-                typedef typename Vec8<T>::type V8;
-                V8 hv, lv;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { hv[i] = hi[i]; lv[i] = NT > 1 ? lo[i] : (T)0.f; }
-                *(V8*)dst = hv;
-                if (NT > 1) *(V8*)(dst + out_plane) = lv;
-            } else {
+        for (int u = 0; u < FPI; ++u) {
+            const int t = f0 + f + u;
+            T hi[CPL], lo[CPL];
 #pragma unroll
-                for (int i = 0; i < CPL; ++i)
-                    if (c0 + i < C) {
-                        dst[i] = hi[i];
-                        if (NT > 1) dst[out_plane + i] = lo[i];
-                    }
+            for (int i = 0; i < CPL; ++i) {
+                float y = gelu_fast((acc[u][i] - mu[u]) * rs[u] * gr[i] + be[i]);
+                split16<T, NT>(y, hi[i], lo[i]);
+            }
+            if (active && t < T1) {
+                T* dst = out + ((int64_t)n * T1 + t) * C + c0;
+                if constexpr (CPL == 8) {
+                    typedef typename Vec8<T>::type V8;
+                    V8 hv, lv;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { hv[i] = hi[i]; lv[i] = NT > 1 ? lo[i] : (T)0.f; }
+                    *(V8*)dst = hv;
+                    if (NT > 1) *(V8*)(dst + out_plane) = lv;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < CPL; ++i)
+                        if (c0 + i < C) {
+                            dst[i] = hi[i];
+                            if (NT > 1) dst[out_plane + i] = lo[i];
+                        }
+                }
             }
         }
     }

@@ -223,16 +223,14 @@ def main():
         }
 
     def load_traffic(precision):
+        """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/, collected with
+        tools/profile_bench.sh as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in separate passes)."""
         pmc_path = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
-        if os.path.exists(pmc_path):
-            try:
-                with open(pmc_path) as f:
-                    rec = json.load(f)
-                if rec.get("precision") == precision:
-                    return rec.get("hbm_bytes_per_launch")
-            except Exception:
-                return None
-        return None
+        try:
+            with open(pmc_path) as f:
+                return json.load(f)[precision]["hbm_bytes_per_launch"]
+        except Exception:
+            return None
 
     elapsed, timing = measure(args.precision, args.steps, args.warmup)
     fl, frames_per_rank, roofline = summarize(args.precision, args.steps, elapsed, timing)

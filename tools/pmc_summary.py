@@ -6,7 +6,7 @@ cnt = collections.defaultdict(lambda: collections.defaultdict(int))
 for path in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(path)):
         name = r["Kernel_Name"]
-        short = name.split("(")[0][-70:]
+        short = name.replace("(anonymous namespace)::", "").split("(")[0][-90:]
         agg[short][r["Counter_Name"]] += float(r["Counter_Value"])
         cnt[short][r["Counter_Name"]] += 1
 out = {}
