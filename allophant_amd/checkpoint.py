@@ -6,10 +6,16 @@ phonetic_indexer_state, dataset_meta_data, model_state, additional, history, opt
 shape the prediction path are read here; the encoder shape is XLS-R-300m (``nn.acoustic_model.model_id``,
 default_config.toml:34-37) unless the checkpoint carries an explicit ``additional["amx_encoder"]`` override (synthetic
 checkpoints used by the plumbing tests -- real hub checkpoints are not reachable offline).
+
+Composition models: upstream rebuilds the embedding-table layout (``_category_offsets``, a non-persistent buffer) from the
+phonetic indexer, which itself is rebuilt from ``phonetic_indexer_state`` = {phoneme_inventory, language_allophones,
+table_file} (phonetic_features.py:111-115, 746-786; acoustic_model.py:191-207, 422-446).  ``indexer_from_checkpoint`` does
+the same from the embedded table text: the training phones are ``language_allophones.shared_phones`` for allophone models
+and ``phoneme_inventory`` otherwise.
 """
 from __future__ import annotations
 
-from typing import Any, Dict
+from typing import Any, Dict, List, Optional, Tuple
 
 import torch
 
@@ -18,8 +24,11 @@ from . import spec as _spec
 XLSR_MODEL_IDS = ("facebook/wav2vec2-xls-r-300m",)
 
 
-def make_checkpoint(spec: Dict[str, Any], state_dict: Dict[str, torch.Tensor], synthetic_encoder: bool = False) -> Dict[str, Any]:
-    """Synthetic checkpoint dict with the reference's field names (used by tests and the config-1 plumbing case)."""
+def make_checkpoint(spec: Dict[str, Any], state_dict: Dict[str, torch.Tensor], synthetic_encoder: bool = False,
+                    indexer_state: Optional[Dict[str, Any]] = None) -> Dict[str, Any]:
+    """Synthetic checkpoint dict with the reference's field names (used by tests and the config-1 plumbing case).
+    With ``indexer_state`` (a ``PhoneticIndexerState`` dump) the composition layout is NOT stored under ``additional``:
+    it has to be rebuilt from the embedded table like upstream does."""
     classes = spec["classes"]
     nodes = [
         {"name": c["name"], "size": c["size"], "time_layer_config": None, "dependencies": list(c["dependencies"])}
@@ -42,7 +51,7 @@ def make_checkpoint(spec: Dict[str, Any], state_dict: Dict[str, torch.Tensor], s
         additional["amx_encoder"] = {k: spec[k] for k in (
             "conv_dim", "conv_kernel", "conv_stride", "hidden", "layers", "heads", "ffn", "pos_kernel", "pos_groups", "eps",
             "do_normalize")}
-    if spec.get("composition_categories") is not None:
+    if spec.get("composition_categories") is not None and indexer_state is None:
         additional["amx_composition_categories"] = list(spec["composition_categories"])
     if spec.get("shared_phones") is not None:
         additional["amx_shared_phones"] = int(spec["shared_phones"])
@@ -55,13 +64,30 @@ def make_checkpoint(spec: Dict[str, Any], state_dict: Dict[str, torch.Tensor], s
         "sample_rate": 16000,
         "attribute_graph": {"nodes": nodes, "node_indices": index, "edges": edges},
         "epoch": {"epoch": 0, "step": 0},
-        "phonetic_indexer_state": None,
+        "phonetic_indexer_state": indexer_state,
         "dataset_meta_data": [],
         "model_state": state_dict,
         "additional": additional,
         "history": [],
         "optimization_states": None,
     }
+
+
+def indexer_from_checkpoint(checkpoint: Dict[str, Any]):
+    """``(AttributeTable, training phones)`` from ``phonetic_indexer_state``, or ``(None, None)`` when the checkpoint has
+    no embedded table."""
+    from .phonetic import AttributeTable
+
+    state = checkpoint.get("phonetic_indexer_state")
+    if not state or not state.get("table_file"):
+        return None, None
+    table = AttributeTable(state["table_file"])
+    allophones = state.get("language_allophones")
+    if allophones and allophones.get("shared_phones"):
+        training = list(allophones["shared_phones"])
+    else:
+        training = list(state.get("phoneme_inventory") or [])
+    return table, training
 
 
 def spec_from_checkpoint(checkpoint: Dict[str, Any]) -> Dict[str, Any]:
@@ -97,6 +123,15 @@ def spec_from_checkpoint(checkpoint: Dict[str, Any]) -> Dict[str, Any]:
     state = checkpoint["model_state"]
     emb_key = "_projection._layers.phoneme._composition_layer._attribute_embeddings.weight"
     spec["composition_categories"] = additional.get("amx_composition_categories")
+    if spec["embedding_size"] and spec["composition_categories"] is None:
+        table, training = indexer_from_checkpoint(checkpoint)
+        if table is not None and training:
+            counts = table.category_counts(training)
+            if emb_key in state and int(state[emb_key].shape[0]) != 1 + sum(counts):
+                raise ValueError(
+                    f"the embedded attribute table yields {1 + sum(counts)} attribute embeddings for the training phones, "
+                    f"the checkpoint holds {int(state[emb_key].shape[0])}")
+            spec["composition_categories"] = counts
     if spec["embedding_size"] and spec["composition_categories"] is None:
         raise ValueError(
             "composition checkpoints need the per-feature category counts (`_category_offsets` is a non-persistent "

@@ -189,15 +189,17 @@ class Estimator:
     @classmethod
     def restore(cls, checkpoint_or_path, device: str = "cuda:0", precision: str = "f16x3"):
         """Builds an estimator from a checkpoint dict in the reference ``Checkpoint`` schema (estimator.py:199-249) or a
-        path to one saved with ``torch.save``.  Returns ``(estimator, attribute_indexer)`` like the reference; the
-        indexer slot is ``None`` (the Allophoible table needed to rebuild it is not reachable offline) -- pass
-        ``composition_feature_matrix`` tensors explicitly as ``target_feature_indices``."""
-        from .checkpoint import spec_from_checkpoint
+        path to one saved with ``torch.save``.  Returns ``(estimator, attribute_indexer)`` like the reference
+        (estimator.py:1085-1126): the indexer is an ``allophant_amd.phonetic.AttributeTable`` rebuilt from the table text
+        embedded in ``phonetic_indexer_state`` (``composition_feature_matrix``, ``phoneme_inventory``,
+        ``composition_features``), or ``None`` for checkpoints without one."""
+        from .checkpoint import indexer_from_checkpoint, spec_from_checkpoint
 
         if not isinstance(checkpoint_or_path, dict):
             checkpoint_or_path = torch.load(checkpoint_or_path, map_location="cpu", weights_only=True)
         spec = spec_from_checkpoint(checkpoint_or_path)
-        return cls(spec, checkpoint_or_path["model_state"], device, precision), None
+        indexer, _training = indexer_from_checkpoint(checkpoint_or_path)
+        return cls(spec, checkpoint_or_path["model_state"], device, precision), indexer
 
     def _set_inventory(self, tfi: Tensor) -> None:
         tfi_cpu = tfi.detach().to("cpu", torch.int64).contiguous()

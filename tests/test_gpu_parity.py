@@ -247,6 +247,38 @@ def test_restore_from_checkpoint_schema(amd, tmp_path):
     est.close()
 
 
+def test_restore_composition_checkpoint_with_embedded_table(amd, tmp_path):
+    """``Estimator.restore`` on a composition + allophone checkpoint whose layout is rebuilt from the embedded attribute
+    table; the returned indexer supplies ``phoneme_inventory`` / ``composition_feature_matrix`` as in the reference's
+    README flow (README.md:69-111), and the prediction matches the oracle on the same inventory."""
+    import json
+
+    from oracle import allophant_oracle as O
+    from test_phonetic_table import GOLDEN, _composition_checkpoint
+
+    with open(GOLDEN, encoding="utf-8") as f:
+        golden = json.load(f)
+    spec, state, ckpt = _composition_checkpoint(golden, True)
+    path = tmp_path / "allophant.pt"
+    torch.save(ckpt, path)
+    est, indexer = amd.Estimator.restore(str(path), "cuda:0")
+    inventory = indexer.phoneme_inventory(["es", "it"])
+    assert inventory == golden["inventories"]["spa+ita"]
+    tfi = indexer.composition_feature_matrix(inventory)
+    audio, lengths = synthetic.make_audio(3, 7000, seed=5, ragged=True)
+    pred = est.predict(amd.Batch(audio.cuda(), lengths, torch.zeros(3, dtype=torch.long)), tfi)
+    assert pred.outputs["phoneme"].shape[-1] == len(inventory) + 1 and "phone" in pred.outputs
+    ref, ref_len = O.predict(audio, lengths, state, spec, tfi, synthetic.category_offsets(spec))
+    for k in ref:
+        assert max_abs_valid_tm(pred.outputs[k].cpu(), ref[k], ref_len) < GATE, k
+    # a different inventory at prediction time (code-switch style): German phones through the same model
+    tfi_de = indexer.composition_feature_matrix(indexer.phoneme_inventory("deu"))
+    pred_de = est.predict(amd.Batch(audio.cuda(), lengths, torch.zeros(3, dtype=torch.long)), tfi_de)
+    ref_de, _ = O.predict(audio, lengths, state, spec, tfi_de, synthetic.category_offsets(spec))
+    assert max_abs_valid_tm(pred_de.outputs["phoneme"].cpu(), ref_de["phoneme"], ref_len) < GATE
+    est.close()
+
+
 def test_xlsr_shape_large_batch_against_oracle(amd):
     """XLS-R-300m shape with N * T >= 1024 rows, so that every large product (conv layers, feature projection, QKV /
     out-proj / FFN, phoneme head) runs on the 256 x 256 ping-pong GEMM and the attention sees ragged key lengths --

@@ -1,0 +1,100 @@
+"""``allophant_amd.phonetic.AttributeTable`` against the REAL reference ``PhoneticAttributeIndexer`` on a synthetic
+Allophoible-format table (tests/golden/g6_phonetic_table.json, written by oracle/gen_phonetic_golden.py): composition
+features, vocabularies, ``composition_feature_matrix``, ``phoneme_inventory`` and the embedding-table category counts."""
+import json
+import os
+
+import pytest
+import torch
+
+from allophant_amd.phonetic import AttributeTable, to_iso6393
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g6_phonetic_table.json")
+
+
+@pytest.fixture(scope="module")
+def golden():
+    with open(GOLDEN, encoding="utf-8") as f:
+        return json.load(f)
+
+
+def test_vocabularies_and_composition_features(golden):
+    table = AttributeTable(golden["table"])
+    assert table.phonemes == golden["phonemes"]
+    assert table.composition_features == golden["composition_features"]
+    assert "tone" not in table.composition_features
+    for feature, categories in golden["feature_categories"].items():
+        assert table.feature_categories(feature) == categories, feature
+
+
+def test_inventories_follow_dialect_preference_and_size(golden):
+    table = AttributeTable(golden["table"])
+    for name, expected in golden["inventories"].items():
+        codes = name.split("+")
+        got = table.phoneme_inventory(codes if len(codes) > 1 else codes[0])
+        assert got == expected, name
+    # 'eng': the configured default dialect (10 phonemes) wins over the larger RP inventory (17)
+    assert len(golden["inventories"]["eng"]) == 10
+    # two-letter codes resolve like upstream's language-code standardisation
+    assert table.phoneme_inventory(["es", "it"]) == golden["inventories"]["spa+ita"]
+    assert to_iso6393("es") == "spa" and to_iso6393("deu") == "deu" and to_iso6393("pt-BR") == "por"
+    with pytest.raises(ValueError):
+        to_iso6393("q")
+
+
+def test_composition_feature_matrix_is_bit_exact(golden):
+    table = AttributeTable(golden["table"])
+    for name, expected in golden["matrices"].items():
+        inventory = ["kp", "a", "t͡s", "ŋ"] if name == "custom" else golden["inventories"][name]
+        got = table.composition_feature_matrix(inventory)
+        assert got.dtype == torch.int64 and got.shape == (len(inventory), len(table.composition_features))
+        assert got.tolist() == expected, name
+    with pytest.raises(ValueError, match="Missing phonemes"):
+        table.composition_feature_matrix(["a", "not-a-phone"])
+
+
+def test_category_counts_match_the_embedding_table_sizes(golden):
+    table = AttributeTable(golden["table"])
+    for name, expected in golden["category_counts"].items():
+        # (row 0 of the embedding table is the blank embedding, acoustic_model.py:193-195; the offsets start after it)
+        assert table.category_counts(golden["inventories"][name]) == expected, name
+
+
+def _composition_checkpoint(golden, allophone_layer):
+    from allophant_amd import checkpoint, spec as S, synthetic
+
+    table = AttributeTable(golden["table"])
+    training = golden["inventories"]["spa+ita"]
+    spec = S.multitask_spec(S.tiny_encoder(1), ["syllabic", "nasal"], embedding_size=16, train_phonemes=len(training),
+                            n_features=len(table.composition_features), allophone_layer=allophone_layer)
+    spec["composition_categories"] = table.category_counts(training)
+    if allophone_layer:
+        spec["shared_phones"] = len(training)
+    state = synthetic.make_state_dict(spec, seed=3)
+    indexer_state = {
+        "phoneme_inventory": training if not allophone_layer else training[:10],
+        "language_allophones": {"allophones": {}, "languages": ["es", "it"], "shared_phones": training} if allophone_layer else None,
+        "table_file": golden["table"],
+    }
+    return spec, state, checkpoint.make_checkpoint(spec, state, synthetic_encoder=True, indexer_state=indexer_state)
+
+
+@pytest.mark.parametrize("allophone_layer", [False, True])
+def test_checkpoint_layout_is_rebuilt_from_the_embedded_table(golden, allophone_layer):
+    """Like upstream, the embedding-table layout of a composition checkpoint comes from ``phonetic_indexer_state`` (table
+    text + training phones), not from a stored buffer."""
+    from allophant_amd import checkpoint
+
+    spec, state, ckpt = _composition_checkpoint(golden, allophone_layer)
+    assert "amx_composition_categories" not in ckpt["additional"]
+    rebuilt = checkpoint.spec_from_checkpoint(ckpt)
+    assert rebuilt["composition_categories"] == spec["composition_categories"]
+    table, training = checkpoint.indexer_from_checkpoint(ckpt)
+    assert training == golden["inventories"]["spa+ita"]
+    assert table.composition_feature_matrix(training).tolist() == golden["matrices"]["spa+ita"]
+    # a table that does not match the stored embedding rows is rejected
+    ckpt["phonetic_indexer_state"]["phoneme_inventory"] = ["a"]
+    if ckpt["phonetic_indexer_state"]["language_allophones"]:
+        ckpt["phonetic_indexer_state"]["language_allophones"]["shared_phones"] = ["a"]
+    with pytest.raises(ValueError, match="attribute embeddings"):
+        checkpoint.spec_from_checkpoint(ckpt)
