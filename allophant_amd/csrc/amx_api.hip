@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -775,10 +776,24 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         g.W = h->conv_w[i]; g.w_plane = (int64_t)C * C * c.conv_kernel[i]; g.ldw = (int64_t)C * c.conv_kernel[i];
         g.M = (int)rows_out; g.N = C; g.K = C * c.conv_kernel[i];
         g.scale = 1.f; g.bias = h->conv_b[i];
-        g.out_f32 = (float*)preln; g.ldo = C;
-        { Timed t_(h, gemm_class(prec, g)); launch_gemm(prec, g, s); }
         const bool last = i == c.n_conv - 1;
         const int64_t out_plane = rows_out * C;
+        if (!last) {
+            // LayerNorm + GELU fused into the GEMM epilogue when the row-complete kernel takes the shape (C == 512)
+            GemmParams f = g;
+            f.act = 1; f.ln_gamma = h->conv_g[i]; f.ln_beta = h->conv_be[i]; f.ln_eps = 1e-5f;
+            f.out_p = other; f.out_plane = out_plane; f.ldp = C;
+            // AMX_NO_FUSED_CONV_LN=1: developer A/B switch (separate fp32 GEMM output + row kernel)
+            const char* no_fuse = getenv("AMX_NO_FUSED_CONV_LN");
+            if (!(no_fuse && no_fuse[0] == '1') && gemm_fuses_ln(prec, f)) {
+                { Timed t_(h, AMX_KC_GEMM_PP); launch_gemm(prec, f, s); }
+                std::swap(cur, other);
+                cur_plane = out_plane;
+                continue;
+            }
+        }
+        g.out_f32 = (float*)preln; g.ldo = C;
+        { Timed t_(h, gemm_class(prec, g)); launch_gemm(prec, g, s); }
         if (!last) {
             { Timed t_(h, AMX_KC_ROWNORM); launch_rownorm(prec, (const float*)preln, C, rows_out, C, h->conv_g[i], h->conv_be[i], 1, nullptr, nullptr, 1e-5f,
                            0.f, other, out_plane, C, nullptr, 0, s); }

@@ -133,6 +133,10 @@ struct GemmParams {
     void* v;
     int64_t qk_plane;  // plane distance of q, k and v
     int T, Tp, H, dh;
+    // fused LayerNorm over the N outputs of a row + GELU (gemm_fuses_ln(); the row-complete 128 x 512 kernel, N == 512)
+    const float* ln_gamma;
+    const float* ln_beta;
+    float ln_eps;
     unsigned long long* stamps;  // developer diagnostic (-DAMX_PP_STAMP builds of tools/gemm_bench.hip), else null
 };
 
@@ -140,6 +144,8 @@ extern bool g_force_generic_gemm;
 void launch_gemm(int prec, const GemmParams& p, hipStream_t stream);
 // true when launch_gemm routes this product to the 256x256 ping-pong kernel (else: generic tile kernel)
 bool gemm_uses_pp(int prec, const GemmParams& p);
+// true when a product with ln_gamma / ln_beta set can run on the row-complete kernel with fused LayerNorm + GELU
+bool gemm_fuses_ln(int prec, const GemmParams& p);
 // same kernel with grid.z = groups (per-group pointer advances za/zw/zbias/zout/zoutp); requires N <= 64
 void launch_gemm_grouped(int prec, const GemmParams& p, int groups, hipStream_t stream);
 

@@ -790,6 +790,340 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Row-complete ping-pong GEMM with fused LayerNorm + GELU (conv layers of the feature extractor, N = 512):
+//   out planes = GELU(LayerNorm_N(A.W^T * scale + bias; gamma, beta, eps))
+// Same pipeline as gemm_pp_kernel (4-slot LDS-DMA ring, two wave groups in anti-phase, three segments per K slice with
+// two planes), but a 128 x 512 tile so that one workgroup owns whole output rows: wave tile 64 x 128 (4 x 8 accumulator
+// fragments), slot = 128 A rows + 512 W rows of 64 B = 40 KiB, ring = the whole 160 KiB LDS.  Per wave and sub-step: 1 DMA
+// piece of A, 4 of W.  The LayerNorm statistics are reduced over the 4 lane groups of a wave (ds_bpermute) and over the
+// 4 waves that share a row block (LDS scratch + barrier), two-pass (mean, then centred variance) like the reference's
+// fp32 LayerNorm; the fp32 pre-normalisation tensor never reaches HBM.
+// ---------------------------------------------------------------------------------------------------------------
+namespace ppw {
+constexpr int BM = 128, BN = 512, KS = 32;
+constexpr int A_BYTES = BM * 64, W_BYTES = BN * 64, SLOT = A_BYTES + W_BYTES, W_OFF = A_BYTES;  // 8 + 32 KiB
+constexpr int LDS_BYTES = 4 * SLOT;                  // 160 KiB
+constexpr int EPI_BASE = 2 * SLOT;                   // patches: slots 2-3 (80 KiB), 8 waves x 8 KiB
+constexpr int RED_BASE = EPI_BASE + 8 * pp::EPI_WAVE;  // 2 x [2 groups][4 waves][64 rows] fp32 = 4 KiB
+constexpr int AJ = 1, WJ = 4;                        // DMA pieces per wave and sub-step
+}  // namespace ppw
+
+template <typename T, int NT>
+__global__ __launch_bounds__(512, 2) void gemm_ln_kernel(const GemmParams p) {
+    typedef typename Vec8<T>::type V8;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wc = wave & 3;
+    const int total = (p.M + ppw::BM - 1) / ppw::BM;  // N == BN: tiles along M only
+
+    const int rd_chunk = ((lane >> 4) ^ ((lane >> 2) & 2)) << 4;
+    const int a_rd = (grp * 64 + (lane & 15)) * 64 + rd_chunk;
+    const int w_rd = ppw::W_OFF + (wc * 128 + (lane & 15)) * 64 + rd_chunk;
+    const uint32_t a_plane_b = (uint32_t)(p.a_plane * 2), w_plane_b = (uint32_t)(p.w_plane * 2);
+
+    int m0 = 0;
+    __amdgpu_buffer_rsrc_t a_rsrc;
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, -1, 0x00020000);
+    uint32_t a_off, w_off[ppw::WJ];
+#pragma unroll
+    for (int j = 0; j < ppw::WJ; ++j) {
+        const int row = (wave * ppw::WJ + j) * 16 + (lane >> 2);
+        const int lc = (lane & 3) ^ ((row >> 2) & 2);
+        w_off[j] = (uint32_t)(((int64_t)row * p.ldw + lc * 8) * 2);
+    }
+    auto setup_tile = [&](int i) {
+        m0 = i * ppw::BM;  // consecutive workgroups take consecutive row blocks: overlapping conv windows share lines
+        const int64_t b0 = m0 / p.rows_per_batch;
+        const int64_t a_tile = b0 * p.a_batch_stride + (m0 - b0 * p.rows_per_batch) * p.lda;
+        a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.A + a_tile), 0, -1, 0x00020000);
+        const int row = wave * 16 + ((tid & 63) >> 2);
+        const int lc = (tid & 3) ^ ((row >> 2) & 2);
+        int rr = m0 + row;
+        rr = rr < p.M ? rr : p.M - 1;
+        const int64_t b = rr / p.rows_per_batch;
+        const int64_t t = rr - b * p.rows_per_batch;
+        a_off = (uint32_t)((b * p.a_batch_stride + t * p.lda - a_tile + lc * 8) * 2);
+    };
+
+    f32x4 acc[8][4];  // [ni][mi]
+    V8 fa[NT][4], fw[NT][8];
+
+    auto stage = [&](int slot, int plane, bool do_a, bool do_w, int koff) {
+        unsigned char* dst = smem + slot * ppw::SLOT;
+        if (do_a)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_ptr_t)(dst + wave * 1024), 16, a_off,
+                                                     plane * a_plane_b + (uint32_t)koff * 2, 0, 0);
+        if (do_w) {
+            const uint32_t so = plane * w_plane_b + (uint32_t)koff * 2;
+#pragma unroll
+            for (int j = 0; j < ppw::WJ; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(dst + ppw::W_OFF + (wave * ppw::WJ + j) * 1024), 16,
+                                                         w_off[j], so, 0, 0);
+        }
+    };
+    auto stage_head = [&]() {
+        if constexpr (NT == 1) {
+            stage(0, 0, true, true, 0);
+            stage(1, 0, true, true, ppw::KS);
+        } else {
+            stage(0, 0, true, true, 0);   // H(0)
+            stage(1, 1, false, true, 0);  // LW(0)
+        }
+    };
+    auto wait_dma = [](int keep) {
+        switch (keep) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        }
+    };
+    // code: RS | RA<<2 | RW<<3 | DPL<<4 | PROD<<5 | SS<<7 | SPL<<9 | RA2<<10 | RW2<<11 (parts staged by the segment two ahead)
+    auto segment = [&](auto code, bool stage_ok, int stage_koff, bool next2_ok) {
+        constexpr int C = decltype(code)::value;
+        constexpr int RS = C & 3, RA = (C >> 2) & 1, RW = (C >> 3) & 1, DPL = (C >> 4) & 1, PROD = (C >> 5) & 3,
+                      SS = (C >> 7) & 3, SPL = (C >> 9) & 1, RA2 = (C >> 10) & 1, RW2 = (C >> 11) & 1;
+        constexpr int CNT3 = ppw::AJ * RA + ppw::WJ * RW, CNT2 = ppw::AJ * RA2 + ppw::WJ * RW2;
+        const int keep = (stage_ok ? CNT3 : 0) + (next2_ok ? CNT2 : 0);
+        const unsigned char* s = smem + RS * ppw::SLOT;
+        if (RA) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) fa[DPL][mi] = *(const V8*)(s + a_rd + mi * 1024);
+        }
+        if (RW) {
+#pragma unroll
+            for (int ni = 0; ni < 8; ++ni) fw[DPL][ni] = *(const V8*)(s + w_rd + ni * 1024);
+        }
+        if (stage_ok) stage(SS, SPL, RA, RW, stage_koff);
+        if (grp == 1) wait_dma(keep);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        constexpr int PW = PROD == 1 ? NT - 1 : 0, PA = PROD == 2 ? NT - 1 : 0;
+#pragma unroll
+        for (int ni = 0; ni < 8; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) mfma16_acc(acc[ni][mi], fw[PW][ni], fa[PA][mi]);
+        __builtin_amdgcn_s_setprio(0);
+        if (grp == 0) wait_dma(keep);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#define PPW_CODE(RS, RA, RW, DPL, PROD, SS, SPL, RA2, RW2) \
+    std::integral_constant<int, (RS) | ((RA) << 2) | ((RW) << 3) | ((DPL) << 4) | ((PROD) << 5) | ((SS) << 7) | ((SPL) << 9) | ((RA2) << 10) | ((RW2) << 11)> {}
+
+    int it = blockIdx.x;
+    setup_tile(it);
+    stage_head();
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (NT == 1) {
+            const int nseg = p.K / ppw::KS;
+            stage(2, 0, true, true, 2 * ppw::KS);
+            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // slice 0 has landed (slices 1, 2 in flight)
+            __builtin_amdgcn_s_barrier();
+            if (grp == 1) __builtin_amdgcn_s_barrier();
+            for (int u = 0; u < nseg; u += 4) {
+                segment(PPW_CODE(0, 1, 1, 0, 0, 3, 0, 1, 1), u + 3 < nseg, (u + 3) * ppw::KS, u + 2 < nseg);
+                segment(PPW_CODE(1, 1, 1, 0, 0, 0, 0, 1, 1), u + 4 < nseg, (u + 4) * ppw::KS, u + 3 < nseg);
+                segment(PPW_CODE(2, 1, 1, 0, 0, 1, 0, 1, 1), u + 5 < nseg, (u + 5) * ppw::KS, u + 4 < nseg);
+                segment(PPW_CODE(3, 1, 1, 0, 0, 2, 0, 1, 1), u + 6 < nseg, (u + 6) * ppw::KS, u + 5 < nseg);
+            }
+        } else {
+            const int nk = p.K / ppw::KS;
+            stage(1, 1, true, false, 0);                      // LA(0): 1 piece
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");  // H(0) has landed (LW(0): 4 pieces, LA(0): 1 in flight)
+            __builtin_amdgcn_s_barrier();
+            if (grp == 1) __builtin_amdgcn_s_barrier();
+            for (int k = 0; k < nk; k += 2) {  // nk is even
+                const bool ok2 = k + 2 < nk;
+                // H: two ahead = LA (A only); LW: two ahead = H (A + W); LA: two ahead = LW (W only)
+                segment(PPW_CODE(0, 1, 1, 0, 0, 2, 0, 1, 0), true, (k + 1) * ppw::KS, true);
+                segment(PPW_CODE(1, 0, 1, 1, 1, 3, 1, 1, 1), true, (k + 1) * ppw::KS, true);
+                segment(PPW_CODE(1, 1, 0, 1, 2, 3, 1, 0, 1), true, (k + 1) * ppw::KS, true);
+                segment(PPW_CODE(2, 1, 1, 0, 0, 0, 0, 1, 0), ok2, (k + 2) * ppw::KS, true);
+                segment(PPW_CODE(3, 0, 1, 1, 1, 1, 1, 1, 1), ok2, (k + 2) * ppw::KS, ok2);
+                segment(PPW_CODE(3, 1, 0, 1, 2, 1, 1, 0, 1), ok2, (k + 2) * ppw::KS, ok2);
+            }
+        }
+        if (grp == 0) __builtin_amdgcn_s_barrier();
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+
+        const int mw = m0 + grp * 64, nw = wc * 128;
+        const int next = it + gridDim.x;
+        const bool has_next = next < total;
+        if (has_next) {
+            setup_tile(next);
+            stage_head();
+        }
+
+        // ---------------- epilogue: bias, LayerNorm over the 512 columns of every row, GELU, planes ----------------
+        asm volatile("" : "+v"(lane));
+        {
+            const int lr = lane & 15, lg = lane >> 4;
+            const float scale = p.scale;
+            float* red = (float*)(smem + ppw::RED_BASE);  // [2 passes][2 groups][4 waves][64 rows]
+            // v = acc * scale + bias
+#pragma unroll
+            for (int ni = 0; ni < 8; ++ni) {
+                const float4 b4 = p.bias ? *(const float4*)(p.bias + nw + ni * 16 + 4 * lg) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    acc[ni][mi][0] = fmaf(acc[ni][mi][0], scale, b4.x);
+                    acc[ni][mi][1] = fmaf(acc[ni][mi][1], scale, b4.y);
+                    acc[ni][mi][2] = fmaf(acc[ni][mi][2], scale, b4.z);
+                    acc[ni][mi][3] = fmaf(acc[ni][mi][3], scale, b4.w);
+                }
+            }
+            const float inv_n = 1.0f / (float)ppw::BN;
+            float mean[4], rstd[4];
+            // pass 0: mean; pass 1: centred variance
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                float part[4];
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int ni = 0; ni < 8; ++ni)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float x = pass == 0 ? acc[ni][mi][r] : (acc[ni][mi][r] - mean[mi]);
+                            s += pass == 0 ? x : x * x;
+                        }
+                    s += __shfl_xor(s, 16);
+                    s += __shfl_xor(s, 32);
+                    part[mi] = s;
+                }
+                float* mine = red + ((pass * 2 + grp) * 4 + wc) * 64;
+                if (lg == 0) {
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) mine[mi * 16 + lr] = part[mi];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                const float* all = red + (pass * 2 + grp) * 4 * 64;
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    const float tot = (all[0 * 64 + mi * 16 + lr] + all[1 * 64 + mi * 16 + lr]) +
+                                      (all[2 * 64 + mi * 16 + lr] + all[3 * 64 + mi * 16 + lr]);
+                    if (pass == 0) mean[mi] = tot * inv_n;
+                    else rstd[mi] = 1.0f / sqrtf(tot * inv_n + p.ln_eps);
+                }
+            }
+            // normalise + affine + GELU in the accumulator layout, then patch -> row-major -> planes
+#pragma unroll
+            for (int ni = 0; ni < 8; ++ni) {
+                const float4 g4 = *(const float4*)(p.ln_gamma + nw + ni * 16 + 4 * lg);
+                const float4 e4 = *(const float4*)(p.ln_beta + nw + ni * 16 + 4 * lg);
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    acc[ni][mi][0] = gelu_fast(fmaf((acc[ni][mi][0] - mean[mi]) * rstd[mi], g4.x, e4.x));
+                    acc[ni][mi][1] = gelu_fast(fmaf((acc[ni][mi][1] - mean[mi]) * rstd[mi], g4.y, e4.y));
+                    acc[ni][mi][2] = gelu_fast(fmaf((acc[ni][mi][2] - mean[mi]) * rstd[mi], g4.z, e4.z));
+                    acc[ni][mi][3] = gelu_fast(fmaf((acc[ni][mi][3] - mean[mi]) * rstd[mi], g4.w, e4.w));
+                }
+            }
+            float* es = (float*)(smem + ppw::EPI_BASE + wave * pp::EPI_WAVE);
+            const int c8 = lane & 7, rs = lane >> 3;
+            // 4 rounds: row halves (mi 0-1 / 2-3) x column halves (ni 0-3 / 4-7), 32 rows x 64 columns each
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int mh = q >> 1, nh = q & 1;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+                        *(f32x4*)(es + pp::es_idx(h * 16 + lr, ni * 4 + lg)) = acc[nh * 4 + ni][mh * 2 + h];
+                f32x4 c[4][2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    c[i][0] = *(const f32x4*)(es + pp::es_idx(i * 8 + rs, 2 * c8));
+                    c[i][1] = *(const f32x4*)(es + pp::es_idx(i * 8 + rs, 2 * c8 + 1));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = mw + mh * 32 + i * 8 + rs;
+                    V8 hv, lv;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        T hi, lo = (T)0.f;
+                        split16<T, NT>(c[i][r >> 2][r & 3], hi, lo);
+                        hv[r] = hi;
+                        lv[r] = lo;
+                    }
+                    if (m < p.M) {
+                        T* dst = (T*)p.out_p + (int64_t)m * p.ldp + nw + nh * 64 + c8 * 8;
+                        *(V8*)dst = hv;
+                        if (NT > 1) *(V8*)(dst + p.out_plane) = lv;
+                    }
+                }
+            }
+        }
+        if (!has_next) break;
+        it = next;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+#undef PPW_CODE
+}
+
+bool ln_eligible(int NT, const GemmParams& p) {
+    if (g_force_generic_gemm) return false;
+    if (!p.ln_gamma || !p.ln_beta || p.act != 1 || !p.out_p || p.out_f32 || p.residual || p.row_len || p.mode != 0) return false;
+    if (p.N != ppw::BN || p.K % (128 / NT) != 0 || p.M < 1024) return false;
+    if (p.lda % 8 || p.ldw % 8 || p.a_plane % 8 || p.w_plane % 8 || p.a_batch_stride % 8) return false;
+    if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return false;
+    if (p.M > p.rows_per_batch && (p.rows_per_batch < 256 || p.a_batch_stride < (p.rows_per_batch - 1) * p.lda)) return false;
+    {
+        const int64_t a_span = (NT > 1 ? p.a_plane : 0) + (p.M > p.rows_per_batch ? p.a_batch_stride : 0) + 256 * p.lda + p.K;
+        const int64_t w_span = (NT > 1 ? p.w_plane : 0) + 512 * p.ldw + p.K;
+        if (a_span < 0 || w_span < 0 || a_span * 2 >= (int64_t)0xFFFFFF00 || w_span * 2 >= (int64_t)0xFFFFFF00) return false;
+    }
+    if (p.bias && ((uintptr_t)p.bias & 15)) return false;
+    if (((uintptr_t)p.ln_gamma & 15) || ((uintptr_t)p.ln_beta & 15)) return false;
+    if (p.ldp % 8 || p.out_plane % 8 || ((uintptr_t)p.out_p & 15)) return false;
+    return true;
+}
+
+template <typename T, int NT>
+void launch_gemm_ln(const GemmParams& p, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_ln_kernel<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, ppw::LDS_BYTES);
+        attr_set = true;
+    }
+    const int tiles = (p.M + ppw::BM - 1) / ppw::BM;
+    int cus = 256;
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        static int cached = 0;
+        if (!cached && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cached = prop.multiProcessorCount;
+        if (cached > 0) cus = cached;
+    }
+    dim3 grid(tiles < cus ? tiles : cus, 1, 1);
+    hipLaunchKernelGGL((gemm_ln_kernel<T, NT>), grid, dim3(512), ppw::LDS_BYTES, stream, p);
+}
+
 bool pp_eligible(int NT, const GemmParams& p) {
     // eligibility: whole sub-step groups, aligned operand rows and vector epilogue, enough rows to fill the chip
     if (g_force_generic_gemm) return false;
@@ -875,10 +1209,22 @@ static GemmParams with_vec_flag(const GemmParams& in) {
     return p;
 }
 
+bool gemm_fuses_ln(int prec, const GemmParams& p_in) { return ln_eligible(prec_planes(prec), with_vec_flag(p_in)); }
+
 bool gemm_uses_pp(int prec, const GemmParams& p_in) { return pp_eligible(prec_planes(prec), with_vec_flag(p_in)); }
 
 void launch_gemm(int prec, const GemmParams& p_in, hipStream_t stream) {
     const GemmParams p = with_vec_flag(p_in);
+    if (p.ln_gamma) {
+        // fused LayerNorm + GELU: only the row-complete kernel implements it (callers check gemm_fuses_ln first)
+        switch (prec) {
+            case PREC_BF16: launch_gemm_ln<bf16, 1>(p, stream); break;
+            case PREC_F16: launch_gemm_ln<f16, 1>(p, stream); break;
+            case PREC_BF16X3: launch_gemm_ln<bf16, 2>(p, stream); break;
+            default: launch_gemm_ln<f16, 2>(p, stream); break;
+        }
+        return;
+    }
     switch (prec) {
         case PREC_BF16: launch_gemm_t<bf16, 1>(p, stream); break;
         case PREC_F16: launch_gemm_t<f16, 1>(p, stream); break;

@@ -13,7 +13,19 @@ est = Estimator(spec, state, torch.device("cuda", 0), prec)
 tfi = synthetic.make_inventory(spec, 27, seed=0)
 audio, lengths = synthetic.make_audio(32, 160000, seed=1234)
 batch = Batch(audio.cuda(), lengths, torch.zeros(32, dtype=torch.long))
-for timing in (False, True, False, True):
+import os
+for fused in ("0", "1", "0", "1"):
+    os.environ["AMX_NO_FUSED_CONV_LN"] = fused
+    for _ in range(3):
+        est.predict(batch, tfi, True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        est.predict(batch, tfi, True)
+    torch.cuda.synchronize()
+    print(f"{prec} AMX_NO_FUSED_CONV_LN={fused}: {(time.perf_counter() - t0) / 10 * 1e3:.3f} ms/step")
+os.environ["AMX_NO_FUSED_CONV_LN"] = "0"
+for timing in (False, True):
     for _ in range(3):
         est.predict(batch, tfi, True, _timing=timing)
     est.timing_fetch()
