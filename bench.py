@@ -129,6 +129,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=device)
 
+    from allophant_amd import parallel
     from allophant_amd.estimator import Batch, Estimator
 
     spec = build_spec()
@@ -148,28 +149,11 @@ def main():
         def step(timing=False):
             pred = est.predict(batch, tfi, True, _timing=timing)
             if world > 1:
-                # RCCL gather of the per-frame log-probabilities (one flat fp32 block per rank) + frame lengths to rank 0
-                flat = pred._flat
-                gathered = [torch.empty_like(flat) for _ in range(world)] if rank == 0 else None
-                dist.gather(flat, gathered, dst=0)
-                lens = pred.lengths.to(device)
-                gl = [torch.empty_like(lens) for _ in range(world)] if rank == 0 else None
-                dist.gather(lens, gl, dst=0)
+                # RCCL gather of the per-frame log-probabilities (one flat fp32 block per rank) + frame lengths to rank 0,
+                # which re-assembles `Predictions` of the global batch: [T, n * world, C] per output
+                gathered = parallel.gather_flat_predictions(pred, device, dst=0)
                 if rank == 0:
-                    # `Predictions` of the global batch on rank 0: [T, n * world, C] per output
-                    T = next(iter(pred.outputs.values())).shape[0]
-                    outputs = {}
-                    done = {}
-                    for name, o in pred.outputs.items():
-                        key = o.data_ptr()
-                        if key in done:
-                            outputs[name] = outputs[done[key]]
-                            continue
-                        c = o.shape[-1]
-                        first = (o.data_ptr() - flat.data_ptr()) // 4
-                        outputs[name] = torch.cat([g[first: first + T * n * c].view(T, n, c) for g in gathered], dim=1)
-                        done[key] = name
-                    return outputs, torch.cat(gl)
+                    return gathered.outputs, gathered.lengths
             return pred.outputs, pred.lengths
 
         for _ in range(warmup):

@@ -10,7 +10,7 @@ import torch.multiprocessing as mp
 
 from allophant_amd import spec as S, synthetic
 from allophant_amd.estimator import Batch, Predictions
-from allophant_amd.parallel import gather_predictions, shard_batch, shard_bounds, unique_outputs
+from allophant_amd.parallel import gather_flat_predictions, gather_predictions, shard_batch, shard_bounds, unique_outputs
 
 
 def _free_port():
@@ -84,3 +84,45 @@ def test_two_rank_gather_matches_single_process(tmp_path):
         valid = (torch.arange(g.shape[0]).unsqueeze(1) < single.lengths.unsqueeze(0)).unsqueeze(-1)
         # sharding re-pads each block to its own longest utterance: identical up to fp32 reassociation
         assert ((g - expected).abs() * valid).max().item() < 1e-4, name
+
+
+def _flat_worker(rank, world, port, result_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # the layout Estimator.predict produces: one flat block, per-output [T, N, C] views, "phone" aliasing "phoneme"
+    t, n = 5, 3
+    widths = [("syllabic", 4), ("phoneme", 7)]
+    g = torch.Generator().manual_seed(100 + rank)
+    flat = torch.randn(sum(t * n * c for _, c in widths), generator=g)
+    outputs, off = {}, 0
+    for name, c in widths:
+        view = flat[off: off + t * n * c].view(t, n, c)
+        if name == "phoneme":
+            outputs["phone"] = view
+        outputs[name] = view
+        off += t * n * c
+    local = Predictions(outputs, torch.tensor([5, 4, 2]) + rank, _flat=flat)
+    gathered = gather_flat_predictions(local, torch.device("cpu"), dst=0)
+    if rank == 0:
+        torch.save({"outputs": gathered.outputs, "lengths": gathered.lengths}, result_path)
+    else:
+        assert gathered is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_gather_assembles_the_global_batch(tmp_path):
+    """The benchmark's gather: equal-shaped shards, one flat block per rank, [T, world * N, C] per output on rank 0."""
+    world = 2
+    result_path = str(tmp_path / "flat.pt")
+    mp.spawn(_flat_worker, args=(world, _free_port(), result_path), nprocs=world, join=True)
+    got = torch.load(result_path)
+    assert list(got["outputs"].keys()) == ["syllabic", "phone", "phoneme"]
+    assert got["lengths"].tolist() == [5, 4, 2, 6, 5, 3]
+    assert got["outputs"]["phone"].data_ptr() == got["outputs"]["phoneme"].data_ptr() or torch.equal(got["outputs"]["phone"], got["outputs"]["phoneme"])
+    for rank in range(world):
+        g = torch.Generator().manual_seed(100 + rank)
+        flat = torch.randn(5 * 3 * 4 + 5 * 3 * 7, generator=g)
+        assert torch.equal(got["outputs"]["syllabic"][:, 3 * rank: 3 * rank + 3], flat[: 60].view(5, 3, 4))
+        assert torch.equal(got["outputs"]["phoneme"][:, 3 * rank: 3 * rank + 3], flat[60:].view(5, 3, 7))
