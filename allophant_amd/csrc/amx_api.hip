@@ -90,8 +90,14 @@ struct amx_handle_s {
         size_t bytes = 0;
     };
     std::map<std::string, WS> ws;
-    int64_t* h_lengths_pinned = nullptr;
-    int* h_frames_pinned = nullptr;
+    // pinned host staging of the per-utterance lengths: a small ring of slots, each guarded by an event recorded behind
+    // its H2D copies, so that a call never waits for the previous forward pass (the host keeps running ahead of the GPU)
+    static constexpr int PIN_SLOTS = 4;
+    int64_t* h_lengths_pinned[PIN_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    int* h_frames_pinned[PIN_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t pin_event[PIN_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    bool pin_busy[PIN_SLOTS] = {false, false, false, false};
+    int pin_next = 0;
     int pinned_cap = 0;
     // per-kernel-class HIP event timing (AMX_FLAG_TIMING)
     struct Span { int cls; hipEvent_t a, b; };
@@ -517,8 +523,11 @@ extern "C" int amx_destroy(amx_handle h) {
     for (void* p : h->allocs) hipFree(p);
     for (auto& kv : h->ws)
         if (kv.second.p) hipFree(kv.second.p);
-    if (h->h_lengths_pinned) hipHostFree(h->h_lengths_pinned);
-    if (h->h_frames_pinned) hipHostFree(h->h_frames_pinned);
+    for (int i = 0; i < amx_handle_s::PIN_SLOTS; ++i) {
+        if (h->h_lengths_pinned[i]) hipHostFree(h->h_lengths_pinned[i]);
+        if (h->h_frames_pinned[i]) hipHostFree(h->h_frames_pinned[i]);
+        if (h->pin_event[i]) hipEventDestroy(h->pin_event[i]);
+    }
     for (auto& sp : h->spans) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
     for (auto e : h->event_pool) hipEventDestroy(e);
     delete h;
@@ -682,20 +691,28 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     if (maxlen != L)
         return fail(h, AMX_EINVAL, "the batch must be padded to exactly max(lengths) (reference utils.py:62-63, acoustic_model.py:765-767)");
 
-    // ---- pinned host staging of lengths ----
+    // ---- pinned host staging of lengths (ring of event-guarded slots: no stream synchronisation on the hot path) ----
     if (h->pinned_cap < N) {
-        if (h->h_lengths_pinned) { hipStreamSynchronize(s); hipHostFree(h->h_lengths_pinned); hipHostFree(h->h_frames_pinned); }
-        HIPCHK(h, hipHostMalloc((void**)&h->h_lengths_pinned, (size_t)N * 8));
-        HIPCHK(h, hipHostMalloc((void**)&h->h_frames_pinned, (size_t)N * 4));
+        HIPCHK(h, hipStreamSynchronize(s));
+        for (int i = 0; i < amx_handle_s::PIN_SLOTS; ++i) {
+            if (h->h_lengths_pinned[i]) { hipHostFree(h->h_lengths_pinned[i]); hipHostFree(h->h_frames_pinned[i]); }
+            HIPCHK(h, hipHostMalloc((void**)&h->h_lengths_pinned[i], (size_t)N * 8));
+            HIPCHK(h, hipHostMalloc((void**)&h->h_frames_pinned[i], (size_t)N * 4));
+            if (!h->pin_event[i]) HIPCHK(h, hipEventCreateWithFlags(&h->pin_event[i], hipEventDisableTiming));
+            h->pin_busy[i] = false;
+        }
         h->pinned_cap = N;
-    } else {
-        HIPCHK(h, hipStreamSynchronize(s));  // previous call may still be reading the pinned buffers
     }
+    const int slot = h->pin_next;
+    h->pin_next = (h->pin_next + 1) % amx_handle_s::PIN_SLOTS;
+    if (h->pin_busy[slot]) HIPCHK(h, hipEventSynchronize(h->pin_event[slot]));  // its copies ran PIN_SLOTS calls ago
+    int64_t* pin_len = h->h_lengths_pinned[slot];
+    int* pin_frames = h->h_frames_pinned[slot];
     for (int n = 0; n < N; ++n) {
-        h->h_lengths_pinned[n] = lengths[n];
+        pin_len[n] = lengths[n];
         int64_t f = frames_of(c, lengths[n]);
         if (lengths[n] < c.conv_kernel[0] || f < 1) return fail(h, AMX_EINVAL, "utterance shorter than the receptive field");
-        h->h_frames_pinned[n] = (int)f;
+        pin_frames[n] = (int)f;
         if (out_lengths) out_lengths[n] = f;
     }
 
@@ -756,8 +773,10 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         conv_dbg = (float*)p;
     }
 
-    HIPCHK(h, hipMemcpyAsync(d_len, h->h_lengths_pinned, (size_t)N * 8, hipMemcpyHostToDevice, s));
-    HIPCHK(h, hipMemcpyAsync(d_frames, h->h_frames_pinned, (size_t)N * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(d_len, pin_len, (size_t)N * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(d_frames, pin_frames, (size_t)N * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipEventRecord(h->pin_event[slot], s));
+    h->pin_busy[slot] = true;
 
     // ---- input normalisation statistics + conv layer 0 (fused norm + conv + LN + GELU) ----
     { Timed t_(h, AMX_KC_OTHER); launch_audio_stats(d_audio, (const int64_t*)d_len, N, L, (double*)d_partial, (float*)d_stats, c.do_normalize, s); }
