@@ -112,6 +112,32 @@ def padding_efficiency(batches: Iterable[Sequence[int]], frame_lengths: Sequence
     return valid / padded if padded else 1.0
 
 
+class PinnedCollator:
+    """``collate`` into a small ring of reusable pinned host buffers (``hipHostMalloc`` per batch costs milliseconds).  A
+    buffer is reused ``depth`` batches later, i.e. after its host-to-device copy has long been consumed."""
+
+    def __init__(self, max_samples: int, depth: int = 3):
+        self._buffers = [torch.empty(max_samples, dtype=torch.float32).pin_memory() for _ in range(depth)]
+        self._next = 0
+
+    def __call__(self, audio: Sequence[Tensor], language_ids: Optional[Sequence[int]] = None) -> Batch:
+        lengths = torch.tensor([int(a.numel()) for a in audio], dtype=torch.int64)
+        longest = int(lengths.max())
+        n = len(audio)
+        buf = self._buffers[self._next]
+        self._next = (self._next + 1) % len(self._buffers)
+        if n * longest > buf.numel():
+            return collate(audio, language_ids, pin=True)  # over-long single utterance: one-off buffer
+        features = buf[: n * longest].view(n, longest)
+        for i, a in enumerate(audio):
+            k = a.numel()
+            features[i, :k].copy_(a.reshape(-1))
+            if k < longest:
+                features[i, k:].zero_()
+        ids = torch.tensor(list(language_ids) if language_ids is not None else [0] * n, dtype=torch.int64)
+        return Batch(features, lengths, ids)
+
+
 class Prefetcher:
     """Iterates device-resident batches: batch k+1 is collated into pinned memory and copied host-to-device on a side
     stream while the caller computes on batch k.  ``batches`` yields CPU ``Batch`` objects (or index lists with ``fetch``)."""

@@ -81,6 +81,7 @@ struct amx_handle_s {
     std::vector<amx_output_desc> outputs;  // relative to N, T of the last layout computation
     std::vector<OutDesc> out_unique, out_all;
     OutDesc *out_unique_dev = nullptr, *out_all_dev = nullptr;
+    int layout_dev_P1 = -1;  // inventory size the device tables were built for
     int layout_N = -1;
     int64_t layout_T = -1;
 
@@ -147,7 +148,8 @@ int ws_get(amx_handle h, const char* name, size_t bytes, void** out, bool zero_o
             w.p = nullptr;
             w.bytes = 0;
         }
-        size_t want = bytes + 256;
+        // grow geometrically: a corpus of ragged batches would otherwise reallocate (and synchronise) every few calls
+        size_t want = bytes + bytes / 4 + 256;
         if (hipMalloc(&w.p, want) != hipSuccess) return fail(h, AMX_ENOMEM, std::string("workspace allocation failed: ") + name);
         w.bytes = want;
         h->ws_bytes += (int64_t)want;
@@ -602,10 +604,10 @@ static int compute_layout(amx_handle h, int N, int64_t L) {
     h->outputs.clear();
     h->out_unique.clear();
     h->out_all.clear();
-    int64_t off = 0;
+    int64_t off = 0, prefix = 0;
     for (int ci : h->order) {
         const amx_class_desc& c = h->classes[ci];
-        OutDesc od{h->col[ci], h->width[ci], off};
+        OutDesc od{h->col[ci], h->width[ci], prefix};
         h->out_unique.push_back(od);
         bool is_phoneme = !strcmp(c.name, "phoneme");
         if (is_phoneme && h->cfg.allophone_layer) {
@@ -623,15 +625,22 @@ static int compute_layout(amx_handle h, int N, int64_t L) {
         h->outputs.push_back(d);
         h->out_all.push_back(od);
         off += (int64_t)T * N * h->width[ci];
+        prefix += h->width[ci];
     }
-    void *a, *b;
-    int rc;
-    if ((rc = ws_get(h, "out_unique", h->out_unique.size() * sizeof(OutDesc), &a))) return rc;
-    if ((rc = ws_get(h, "out_all", h->out_all.size() * sizeof(OutDesc), &b))) return rc;
-    HIPCHK(h, hipMemcpy(a, h->out_unique.data(), h->out_unique.size() * sizeof(OutDesc), hipMemcpyHostToDevice));
-    HIPCHK(h, hipMemcpy(b, h->out_all.data(), h->out_all.size() * sizeof(OutDesc), hipMemcpyHostToDevice));
-    h->out_unique_dev = (OutDesc*)a;
-    h->out_all_dev = (OutDesc*)b;
+    // The device tables hold (column, classes, class prefix) only -- independent of (N, T) -- so they are uploaded when the
+    // inventory changes (layout_dev_P1), never on a mere geometry change: no copy races a forward pass still in flight.
+    if (!h->out_unique_dev || h->layout_dev_P1 != h->P1) {
+        void *a, *b;
+        int rc;
+        HIPCHK(h, hipDeviceSynchronize());
+        if ((rc = ws_get(h, "out_unique", h->out_unique.size() * sizeof(OutDesc), &a))) return rc;
+        if ((rc = ws_get(h, "out_all", h->out_all.size() * sizeof(OutDesc), &b))) return rc;
+        HIPCHK(h, hipMemcpy(a, h->out_unique.data(), h->out_unique.size() * sizeof(OutDesc), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(b, h->out_all.data(), h->out_all.size() * sizeof(OutDesc), hipMemcpyHostToDevice));
+        h->out_unique_dev = (OutDesc*)a;
+        h->out_all_dev = (OutDesc*)b;
+        h->layout_dev_P1 = h->P1;
+    }
     h->layout_N = N;
     h->layout_T = T;
     return AMX_OK;

@@ -194,7 +194,8 @@ void launch_concat(int prec, const ConcatPart* parts_dev, int n_parts, const flo
 struct OutDesc {
     int col;          // column offset in the logits buffer
     int C;            // classes incl. blank
-    int64_t out_off;  // offset (floats) of the [T,N,C] block in the output buffer
+    int64_t prefix;   // classes of all earlier output blocks: the [T,N,C] block starts at T * N * prefix floats
+                      // (geometry-independent, so the device table only changes with the inventory)
 };
 void launch_logsoftmax_out(const OutDesc* descs_dev, int n_out, const float* logits, int64_t ld, int N, int T,
                            int log_probs, float* out, hipStream_t s);

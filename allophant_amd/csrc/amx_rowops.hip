@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void logsoftmax_out_kernel(const OutDesc* __re
     for (int o = 0; o < n_out; ++o) {
         const OutDesc d = descs[o];
         const float* src = src_row + d.col;
-        float* dst = out + d.out_off + ((int64_t)t * N + n) * d.C;
+        float* dst = out + (int64_t)T * N * d.prefix + ((int64_t)t * N + n) * d.C;
         float lse = 0.f;
         if (log_probs) {
             float m = -INFINITY;
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void greedy_ctc_kernel(const OutDesc* __restri
     const int o = blockIdx.y, n = blockIdx.x;
     const OutDesc d = descs[o];
     const int len = frame_len[n] < T ? frame_len[n] : T;
-    const float* base = out + d.out_off;
+    const float* base = out + (int64_t)T * N * d.prefix;
     float score = 0.f;
     for (int t = threadIdx.x; t < len; t += 256) {
         const float* p = base + ((int64_t)t * N + n) * d.C;

@@ -52,3 +52,20 @@ def test_utterance_batches_and_sorted_order():
     corpus = list(B.max_frame_batches(range(300), lens, 32 * 160000))
     sorted_ = list(B.max_frame_batches(B.length_sorted_order(lens), lens, 32 * 160000))
     assert B.padding_efficiency(sorted_, lens) > 0.9 > 0.7 > B.padding_efficiency(corpus, lens)
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_pinned_collator_equals_collate():
+    if not torch.cuda.is_available():
+        import pytest
+        pytest.skip("pinned host memory needs the HIP runtime")
+    audio = [torch.randn(n) for n in (5, 9, 3)]
+    ring = B.PinnedCollator(64, depth=2)
+    for _ in range(3):  # buffers are reused: stale tails must be re-zeroed
+        got = ring(audio, [1, 1, 2])
+        ref = B.collate(audio, [1, 1, 2])
+        assert torch.equal(got.audio_features, ref.audio_features) and torch.equal(got.lengths, ref.lengths)
+        audio = audio[::-1]

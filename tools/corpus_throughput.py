@@ -24,7 +24,8 @@ budget = 32 * 160000  # the padded size of BASELINE config 2
 
 def run(order, label):
     batches = [b for b in B.max_frame_batches(order, lengths, budget) if b]
-    fetch = lambda idx: B.collate([audio[i] for i in idx], pin=True)
+    collator = B.PinnedCollator(budget)
+    fetch = lambda idx: collator([audio[i] for i in idx])
     for warm in (True, False):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -38,5 +39,6 @@ def run(order, label):
           f"{frames / dt:.0f} valid frames/s ({dt:.2f} s for {sum(lengths) / 16000:.0f} s of audio)", flush=True)
 
 
+import cProfile  # noqa: E402
 run(range(n_utt), "corpus order   ")
 run(B.length_sorted_order(lengths), "length-sorted  ")
