@@ -139,38 +139,28 @@ class PinnedCollator:
 
 
 class Prefetcher:
-    """Iterates device-resident batches: batch k+1 is collated into pinned memory and copied host-to-device on a side
-    stream while the caller computes on batch k.  ``batches`` yields CPU ``Batch`` objects (or index lists with ``fetch``)."""
+    """Iterates device-resident batches.  Each ``next()`` collates one batch into pinned memory and copies it to the device
+    on a side stream; because ``Estimator.predict`` only *launches* work, the caller's call for batch k+1 arrives while the
+    GPU is still computing batch k, so the host-side collation and the host-to-device copy of k+1 overlap the compute of k
+    (the compute stream waits for the copy only when it actually consumes the batch).  ``batches`` yields CPU ``Batch``
+    objects, or anything ``fetch`` turns into one (e.g. index lists)."""
 
     def __init__(self, batches: Iterable, device: torch.device, fetch=None):
         self._source = iter(batches)
         self._device = torch.device(device)
         self._fetch = fetch
         self._stream = torch.cuda.Stream(self._device)
-        self._next = None
-        self._preload()
-
-    def _preload(self) -> None:
-        try:
-            item = next(self._source)
-        except StopIteration:
-            self._next = None
-            return
-        batch = self._fetch(item) if self._fetch is not None else item
-        audio = batch.audio_features if batch.audio_features.is_pinned() else batch.audio_features.pin_memory()
-        with torch.cuda.stream(self._stream):
-            dev = audio.to(self._device, non_blocking=True)
-        self._next = (Batch(dev, batch.lengths, batch.language_ids), audio)
 
     def __iter__(self):
         return self
 
     def __next__(self) -> Batch:
-        if self._next is None:
-            raise StopIteration
-        batch, _pinned = self._next
+        item = next(self._source)
+        batch = self._fetch(item) if self._fetch is not None else item
+        audio = batch.audio_features if batch.audio_features.is_pinned() else batch.audio_features.pin_memory()
+        with torch.cuda.stream(self._stream):
+            dev = audio.to(self._device, non_blocking=True)
         current = torch.cuda.current_stream(self._device)
-        current.wait_stream(self._stream)                 # the copy of this batch is ordered before its consumers
-        batch.audio_features.record_stream(current)
-        self._preload()                                   # overlaps the next copy with the caller's compute
-        return batch
+        current.wait_stream(self._stream)  # stream-ordered: later launches on the compute stream see the copied batch
+        dev.record_stream(current)
+        return Batch(dev, batch.lengths, batch.language_ids)
