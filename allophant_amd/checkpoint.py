@@ -24,6 +24,15 @@ from . import spec as _spec
 XLSR_MODEL_IDS = ("facebook/wav2vec2-xls-r-300m",)
 
 
+def _time_config(c: Dict[str, Any]) -> Optional[Dict[str, Any]]:
+    """``MultiheadAttentionConfig`` dump of a class's ``time_layer`` (config.py:596-610)."""
+    layer = c.get("time_layer")
+    if not layer:
+        return None
+    return {"type": "multi-head-attention", "num_heads": int(layer.get("num_heads", 1)),
+            "positional_embeddings": bool(layer.get("positional_embeddings", False))}
+
+
 def make_checkpoint(spec: Dict[str, Any], state_dict: Dict[str, torch.Tensor], synthetic_encoder: bool = False,
                     indexer_state: Optional[Dict[str, Any]] = None) -> Dict[str, Any]:
     """Synthetic checkpoint dict with the reference's field names (used by tests and the config-1 plumbing case).
@@ -31,13 +40,13 @@ def make_checkpoint(spec: Dict[str, Any], state_dict: Dict[str, torch.Tensor], s
     it has to be rebuilt from the embedded table like upstream does."""
     classes = spec["classes"]
     nodes = [
-        {"name": c["name"], "size": c["size"], "time_layer_config": None, "dependencies": list(c["dependencies"])}
+        {"name": c["name"], "size": c["size"], "time_layer_config": _time_config(c), "dependencies": list(c["dependencies"])}
         for c in classes
     ]
     index = {c["name"]: i for i, c in enumerate(classes)}
     edges = [[index[d] for d in c["dependencies"] if not _spec.OUTPUT_PATTERN.match(d)] for c in classes]
     projection = {
-        "classes": [{"name": c["name"], "dependencies": list(c["dependencies"]), "time_layer": None, "loss": {"type": "CTC"}}
+        "classes": [{"name": c["name"], "dependencies": list(c["dependencies"]), "time_layer": _time_config(c), "loss": {"type": "CTC"}}
                     for c in classes],
         "feature_set": "phoible",
         "phoneme_layer": "allophones" if spec.get("allophone_layer") else "shared",
@@ -110,12 +119,14 @@ def spec_from_checkpoint(checkpoint: Dict[str, Any]) -> Dict[str, Any]:
         raise ValueError(f"Unsupported model type: {acoustic.get('type')!r} / {acoustic.get('model_id')!r}")
     projection = nn_config["projection"]
     spec = dict(encoder)
-    spec["classes"] = [
-        {"name": n["name"], "size": int(n["size"]), "dependencies": list(n["dependencies"])}
-        for n in checkpoint["attribute_graph"]["nodes"]
-    ]
-    if any(n.get("time_layer_config") for n in checkpoint["attribute_graph"]["nodes"]):
-        raise ValueError("classifiers with a `time_layer` are not supported by the MI355X path yet")
+    spec["classes"] = []
+    for n in checkpoint["attribute_graph"]["nodes"]:
+        entry = {"name": n["name"], "size": int(n["size"]), "dependencies": list(n["dependencies"])}
+        layer = n.get("time_layer_config")
+        if layer:
+            entry["time_layer"] = {"num_heads": int(layer.get("num_heads", 1)),
+                                   "positional_embeddings": bool(layer.get("positional_embeddings", False))}
+        spec["classes"].append(entry)
     spec["dependency_blanks"] = bool(projection.get("dependency_blanks", True))
     composition = projection.get("embedding_composition")
     spec["embedding_size"] = int(composition["embedding_size"]) if composition else None

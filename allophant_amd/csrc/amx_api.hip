@@ -36,6 +36,13 @@ struct HeadStep {
     int rows;                   // sum of out_features
     bool composed;              // rows == embedding_size, followed by the composition product
     ConcatPart* parts_dev;
+    std::vector<ConcatPart> parts_uploaded;  // what parts_dev currently holds (re-uploaded only when it changes)
+    // time layer (ProjectingMultiheadAttention, acoustic_model.py:237-268): W / bias are its input_projection and the
+    // step continues LayerNorm(+positions) -> in_proj -> key-masked attention over time -> out_proj
+    int time_heads = 0;         // 0: plain linear classifier
+    int Cpad = 0;               // rows rounded up to 8 (K of the in_proj / out_proj products)
+    float *tl_g = nullptr, *tl_b = nullptr, *tl_bin = nullptr, *tl_bout = nullptr, *tl_pe = nullptr;
+    void *tl_win = nullptr, *tl_wout = nullptr;
 };
 
 }  // namespace
@@ -311,6 +318,15 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
             if (!strncmp(c.name, h->classes[j].name, AMX_NAME_LEN)) { h->err = "Dependencies contain duplicate keys"; return bail(AMX_EINVAL); }
         if (!strncmp(c.name, "OUTPUT", 6)) { h->err = "'OUTPUT' is a reserved keyword"; return bail(AMX_EINVAL); }
         if (c.n_deps < 1 || c.n_deps > AMX_MAX_DEPS) { h->err = "Each class projection requires a dependency"; return bail(AMX_EINVAL); }
+        if (c.out_features < 1) { h->err = "classifier without outputs"; return bail(AMX_EINVAL); }
+        if (c.time_heads < 0 || (c.time_heads > 0 && c.out_features % c.time_heads)) {
+            h->err = "embed_dim must be divisible by num_heads";  // nn.MultiheadAttention's assertion
+            return bail(AMX_EINVAL);
+        }
+        if (c.time_heads > 0 && c.time_positional && (c.out_features & 1)) {
+            h->err = "sinusoidal position embeddings need an even number of classifier outputs";
+            return bail(AMX_EINVAL);
+        }
         for (int d = 0; d < c.n_deps; ++d) {
             if (c.deps[d] < 0) {
                 uses_output = true;
@@ -456,7 +472,8 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
             if (c.deps[d] < -1) h->need_hidden[-2 - c.deps[d]] = true;
         }
         // stack onto the previous step when both read the final LayerNorm output directly and neither is composed
-        if (direct && !composed && !h->steps.empty() && h->steps.back().direct_output && !h->steps.back().composed) {
+        if (direct && !composed && c.time_heads == 0 && !h->steps.empty() && h->steps.back().direct_output &&
+            !h->steps.back().composed && h->steps.back().time_heads == 0) {
             h->steps.back().classes.push_back(ci);
             h->steps.back().rows += c.out_features;
             continue;
@@ -469,6 +486,8 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
         st.rows = c.out_features;
         st.composed = composed;
         st.parts_dev = nullptr;
+        st.time_heads = c.time_heads;
+        st.Cpad = round_up(c.out_features, 8);
         if (!direct) {
             int colp = 0;
             for (int d = 0; d < c.n_deps; ++d) {
@@ -494,6 +513,35 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
         for (int ci : st.classes) {
             const amx_class_desc& c = h->classes[ci];
             std::string p = PROJ + c.name + "._time_distributed_layer.";
+            if (st.time_heads > 0) {
+                // module tree of ProjectingMultiheadAttention: input_projection, layer_norm, attention (nn.MultiheadAttention)
+                const int Co = c.out_features;
+                const int64_t plane_in = (int64_t)3 * Co * st.Cpad, plane_out = (int64_t)Co * st.Cpad;
+                st.tl_win = alloc_planes(h, plane_in);
+                st.tl_wout = alloc_planes(h, plane_out);
+                if (!st.tl_win || !st.tl_wout) { h->err = "device allocation failed"; return bail(AMX_ENOMEM); }
+                TRY(pack_linear(h, tm, p + "attention.in_proj_weight", 3 * Co, Co, 1.f, st.tl_win, plane_in, st.Cpad, 0, st.Cpad, staging));
+                TRY(pack_linear(h, tm, p + "attention.out_proj.weight", Co, Co, 1.f, st.tl_wout, plane_out, st.Cpad, 0, st.Cpad, staging));
+                TRY(upload_f32(h, tm, p + "attention.in_proj_bias", 3 * Co, &st.tl_bin));
+                TRY(upload_f32(h, tm, p + "attention.out_proj.bias", Co, &st.tl_bout));
+                TRY(upload_f32(h, tm, p + "layer_norm.weight", Co, &st.tl_g));
+                TRY(upload_f32(h, tm, p + "layer_norm.bias", Co, &st.tl_b));
+                if (c.time_positional) {
+                    // SinusoidalPositionEmbeddings (acoustic_model.py:34-69): base_k = exp(-2k ln(1e4) / size) for the
+                    // column pair (2k, 2k+1)
+                    std::vector<float> base(Co);
+                    // fp32 like upstream: arange(0, size, 2) * float(-ln(1e4) / size), then exp
+                    const float step = (float)(-(std::log(10000.0) / Co));
+                    for (int col = 0; col < Co; ++col) {
+                        volatile float arg = (float)(col & ~1) * step;
+                        base[col] = (float)std::exp((double)arg);
+                    }
+                    st.tl_pe = (float*)dev_alloc(h, (size_t)Co * 4);
+                    if (!st.tl_pe) { h->err = "device allocation failed"; return bail(AMX_ENOMEM); }
+                    if (hipMemcpy(st.tl_pe, base.data(), (size_t)Co * 4, hipMemcpyHostToDevice) != hipSuccess) { h->err = "H2D failed"; return bail(AMX_EHIP); }
+                }
+                p += "input_projection.";
+            }
             TRY(pack_linear(h, tm, p + "weight", c.out_features, st.K, 1.f, st.W, (int64_t)st.rows * st.Kpad, st.Kpad, row0, st.Kpad, staging));
             const amx_tensor* b = tm.get(p + "bias");
             if (!b || b->numel != c.out_features) { h->err = "missing tensor " + p + "bias"; return bail(AMX_EINVAL); }
@@ -930,6 +978,21 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     for (auto& st : h->steps) kcat = std::max(kcat, st.direct_output ? 0 : st.Kpad);
     if (E > 0) WS("e", (size_t)M * E * 2 * NT, ebuf);
     if (kcat > 0) WS("cat", (size_t)M * kcat * 2 * NT, cat);
+    void *tl_x = nullptr, *tl_p = nullptr, *tl_qkv = nullptr;
+    {
+        int cmax = 0;
+        for (auto& st : h->steps)
+            if (st.time_heads > 0) {
+                cmax = std::max(cmax, st.Cpad);
+                if (time_attention_lds_bytes(T, st.rows / st.time_heads) > 160 * 1024)
+                    return fail(h, AMX_EINVAL, "utterance too long for the time-layer attention (frames + head_dim > 10240)");
+            }
+        if (cmax > 0) {
+            WS("tl_x", (size_t)M * cmax * 4, tl_x);
+            WS("tl_p", (size_t)M * cmax * 2 * NT, tl_p);
+            WS("tl_qkv", (size_t)M * cmax * 3 * 4, tl_qkv);
+        }
+    }
     const bool blanks = c.dependency_blanks != 0;
     for (auto& st : h->steps) {
         const void* A = xp;
@@ -948,8 +1011,14 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
                         return fail(h, AMX_EINVAL, "inventory size does not match the input width of a dependent classifier");
                 }
             }
-            HIPCHK(h, hipMemcpyAsync(st.parts_dev, st.parts.data(), st.parts.size() * sizeof(ConcatPart), hipMemcpyHostToDevice, s));
-            HIPCHK(h, hipStreamSynchronize(s));  // st.parts is pageable host memory
+            if (st.parts_uploaded.size() != st.parts.size() ||
+                memcmp(st.parts_uploaded.data(), st.parts.data(), st.parts.size() * sizeof(ConcatPart)) != 0) {
+                // the recipe only changes with the workspace pointers or the inventory; st.parts is pageable host memory,
+                // so this (rare) upload completes before the call goes on
+                HIPCHK(h, hipMemcpyAsync(st.parts_dev, st.parts.data(), st.parts.size() * sizeof(ConcatPart), hipMemcpyHostToDevice, s));
+                HIPCHK(h, hipStreamSynchronize(s));
+                st.parts_uploaded = st.parts;
+            }
             { Timed t_(h, AMX_KC_OTHER); launch_concat(prec, st.parts_dev, (int)st.parts.size(), (const float*)logits, h->ld_logits, M, cat, M * st.Kpad,
                           st.Kpad, st.Kpad, s); }
             A = cat; a_plane = M * st.Kpad; lda = st.Kpad;
@@ -959,6 +1028,29 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         g.W = st.W; g.w_plane = (int64_t)st.rows * st.Kpad; g.ldw = st.Kpad;
         g.M = (int)M; g.N = st.rows; g.K = st.Kpad;
         g.scale = 1.f; g.bias = st.bias;
+        if (st.time_heads > 0) {
+            // ProjectingMultiheadAttention.forward (acoustic_model.py:255-268)
+            const int Co = st.rows, Cp = st.Cpad;
+            g.out_f32 = (float*)tl_x; g.ldo = Co;
+            { Timed t_(h, gemm_class(prec, g)); launch_gemm(prec, g, s); }
+            { Timed t_(h, AMX_KC_OTHER); launch_time_ln_pe(prec, (const float*)tl_x, M, Co, T, st.tl_g, st.tl_b, 1e-5f, st.tl_pe, tl_p,
+                              M * Cp, Cp, s); }
+            GemmParams gi{};
+            gi.A = tl_p; gi.a_plane = M * Cp; gi.lda = Cp; gi.rows_per_batch = M;
+            gi.W = st.tl_win; gi.w_plane = (int64_t)3 * Co * Cp; gi.ldw = Cp;
+            gi.M = (int)M; gi.N = 3 * Co; gi.K = Cp;
+            gi.scale = 1.f; gi.bias = st.tl_bin;
+            gi.out_f32 = (float*)tl_qkv; gi.ldo = 3 * Co;
+            { Timed t_(h, gemm_class(prec, gi)); launch_gemm(prec, gi, s); }
+            { Timed t_(h, AMX_KC_OTHER); launch_time_attention(prec, (const float*)tl_qkv, (const int*)d_frames, N, T, Co, st.time_heads,
+                                  tl_p, M * Cp, Cp, s); }
+            // out_proj lands where the plain linear classifier would have written
+            g = GemmParams{};
+            g.A = tl_p; g.a_plane = M * Cp; g.lda = Cp; g.rows_per_batch = M;
+            g.W = st.tl_wout; g.w_plane = (int64_t)Co * Cp; g.ldw = Cp;
+            g.M = (int)M; g.N = Co; g.K = Cp;
+            g.scale = 1.f; g.bias = st.tl_bout;
+        }
         if (st.composed) {
             g.out_p = ebuf; g.out_plane = M * E; g.ldp = E;
             { Timed t_(h, gemm_class(prec, g)); launch_gemm(prec, g, s); }

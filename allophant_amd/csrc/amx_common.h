@@ -191,6 +191,14 @@ struct ConcatPart {
 void launch_concat(int prec, const ConcatPart* parts_dev, int n_parts, const float* logits, int64_t ld_logits, int64_t M,
                    void* out, int64_t out_plane, int64_t ldp, int kpad, hipStream_t s);
 
+// time-layer classifier heads (ProjectingMultiheadAttention): LayerNorm + sinusoidal positions -> planes [M, kpad];
+// key-masked fp32 attention over the frames of each utterance on qkv [M, 3C] -> planes [M, kpad]
+void launch_time_ln_pe(int prec, const float* x, int64_t M, int C, int T, const float* gamma, const float* beta, float eps,
+                       const float* pe_base /*[C] or null*/, void* out, int64_t out_plane, int kpad, hipStream_t s);
+size_t time_attention_lds_bytes(int T, int dh);
+void launch_time_attention(int prec, const float* qkv, const int* frame_len, int N, int T, int C, int heads, void* out,
+                           int64_t out_plane, int kpad, hipStream_t s);
+
 struct OutDesc {
     int col;          // column offset in the logits buffer
     int C;            // classes incl. blank

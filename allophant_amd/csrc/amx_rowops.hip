@@ -336,6 +336,108 @@ __global__ __launch_bounds__(256) void concat_kernel(const ConcatPart* __restric
 }
 
 // ----------------------------------------------------------------------------------------------------------------
+// time-layer classifier heads (ProjectingMultiheadAttention, reference acoustic_model.py:237-268)
+// ----------------------------------------------------------------------------------------------------------------
+// LayerNorm(C) of the projected rows + sinusoidal positions (acoustic_model.py:34-69: column 2k = sin(t * base_k),
+// column 2k+1 = cos(t * base_k); `pe_base` holds base per column) -> 16-bit planes [M, kpad] for the in_proj product.
+// One wave per row (row = n*T + t); C is arbitrary (class sizes are small, the composed head has C = embedding_size).
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void time_ln_pe_kernel(const float* __restrict__ x, int64_t M, int C, int T_frames,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float eps, const float* __restrict__ pe_base,
+                                                         T* __restrict__ out, int64_t out_plane, int kpad) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* src = x + row * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += src[c];
+    const float mu = wave_sum(s) / (float)C;
+    float q = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        float d = src[c] - mu;
+        q += d * d;
+    }
+    const float rs = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+    const float t = (float)(row % T_frames);
+    T* dst = out + row * kpad;
+    for (int c = lane; c < kpad; c += 64) {
+        float y = 0.f;
+        if (c < C) {
+            y = (src[c] - mu) * rs * gamma[c] + beta[c];
+            if (pe_base) {
+                const float arg = t * pe_base[c];
+                y += (c & 1) ? cosf(arg) : sinf(arg);
+            }
+        }
+        T hi, lo;
+        split16<T, NT>(y, hi, lo);
+        dst[c] = hi;
+        if (NT > 1) dst[out_plane + c] = lo;
+    }
+}
+
+// softmax(q k^T / sqrt(dh) masked to the valid keys of the utterance) v over the frames of one utterance, fp32 on the
+// vector ALU: one wave per (utterance, head, query frame).  Lanes are (key group, d) pairs: DP = pow2 >= min(dh, 64)
+// lanes hold the dh axis, 64 / DP groups stride over the keys.  Scores go through LDS (T floats per wave).
+// Queries of padded frames are computed like upstream (only keys are masked, nn.MultiheadAttention key_padding_mask).
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void time_attention_kernel(const float* __restrict__ qkv, const int* __restrict__ frame_len,
+                                                             int T_frames, int C, int dh, int dp, T* __restrict__ out,
+                                                             int64_t out_plane, int kpad) {
+    extern __shared__ float time_lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = blockIdx.x * 4 + wave, hd = blockIdx.y, n = blockIdx.z;
+    if (t >= T_frames) return;
+    float* sc = time_lds + (size_t)wave * (T_frames + dh);
+    float* qs = sc + T_frames;
+    const int64_t ld = 3 * (int64_t)C;
+    const float* base = qkv + (int64_t)n * T_frames * ld + hd * dh;
+    const float scale = 1.0f / sqrtf((float)dh);
+    for (int d = lane; d < dh; d += 64) qs[d] = base[(int64_t)t * ld + d] * scale;
+    const int len = frame_len[n];
+    float m = -INFINITY;
+    for (int key = lane; key < len; key += 64) {
+        const float* kr = base + (int64_t)key * ld + C;
+        float a = 0.f;
+        for (int d = 0; d < dh; ++d) a = fmaf(qs[d], kr[d], a);
+        sc[key] = a;
+        m = fmaxf(m, a);
+    }
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int key = lane; key < len; key += 64) {
+        float e = expf(sc[key] - m);
+        sc[key] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    const int groups = 64 / dp, kg = lane / dp, dl = lane % dp;
+    const int64_t orow = ((int64_t)n * T_frames + t) * kpad;
+    for (int d0 = 0; d0 < dh; d0 += dp) {
+        const int d = d0 + dl;
+        float o = 0.f;
+        if (d < dh) {
+            const float* vr = base + 2 * C + d;
+            for (int key = kg; key < len; key += groups) o = fmaf(sc[key], vr[(int64_t)key * ld], o);
+        }
+        for (int off = dp; off < 64; off <<= 1) o += __shfl_xor(o, off);
+        if (kg == 0 && d < dh) {
+            T hi, lo;
+            split16<T, NT>(o * inv, hi, lo);
+            out[orow + hd * dh + d] = hi;
+            if (NT > 1) out[out_plane + orow + hd * dh + d] = lo;
+        }
+    }
+    if (hd == 0)
+        for (int c = C + lane; c < kpad; c += 64) {
+            out[orow + c] = (T)0.f;
+            if (NT > 1) out[out_plane + orow + c] = (T)0.f;
+        }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
 // per-head log-softmax (reference estimator.py:1041-1045), batch-major logits -> time-major [T,N,C] outputs
 // ----------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void logsoftmax_out_kernel(const OutDesc* __restrict__ descs, int n_out,
@@ -593,6 +695,33 @@ void launch_concat(int prec, const ConcatPart* parts_dev, int n_parts, const flo
     dim3 grid((unsigned)((M + 3) / 4));
     AMX_DISPATCH(prec, hipLaunchKernelGGL((concat_kernel<T16, NT>), grid, dim3(256), 0, s, parts_dev, n_parts, logits,
                                           ld_logits, M, (T16*)out, out_plane, ldp, kpad));
+}
+
+void launch_time_ln_pe(int prec, const float* x, int64_t M, int C, int T, const float* gamma, const float* beta, float eps,
+                       const float* pe_base, void* out, int64_t out_plane, int kpad, hipStream_t s) {
+    dim3 grid((unsigned)((M + 3) / 4));
+    AMX_DISPATCH(prec, hipLaunchKernelGGL((time_ln_pe_kernel<T16, NT>), grid, dim3(256), 0, s, x, M, C, T, gamma, beta, eps,
+                                          pe_base, (T16*)out, out_plane, kpad));
+}
+
+size_t time_attention_lds_bytes(int T, int dh) { return (size_t)4 * (T + dh) * sizeof(float); }
+
+template <typename T, int NT>
+static void time_attention_launch(const float* qkv, const int* frame_len, int N, int T_frames, int C, int heads, void* out,
+                                  int64_t out_plane, int kpad, hipStream_t s) {
+    const int dh = C / heads;
+    int dp = 1;
+    while (dp < dh && dp < 64) dp <<= 1;
+    const size_t lds = time_attention_lds_bytes(T_frames, dh);
+    auto kernel = time_attention_kernel<T, NT>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)((T_frames + 3) / 4), heads, N), dim3(256), lds, s, qkv, frame_len, T_frames, C,
+                       dh, dp, (T*)out, out_plane, kpad);
+}
+
+void launch_time_attention(int prec, const float* qkv, const int* frame_len, int N, int T, int C, int heads, void* out,
+                           int64_t out_plane, int kpad, hipStream_t s) {
+    AMX_DISPATCH(prec, (time_attention_launch<T16, NT>(qkv, frame_len, N, T, C, heads, out, out_plane, kpad, s)));
 }
 
 void launch_logsoftmax_out(const OutDesc* descs_dev, int n_out, const float* logits, int64_t ld, int N, int T,

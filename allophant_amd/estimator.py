@@ -119,6 +119,9 @@ def _spec_to_structs(spec: Dict[str, Any], precision: str):
         allophone = c["name"] == _spec.PHONEME and cfg.allophone_layer
         out_classes = spec.get("shared_phones", c["size"]) if allophone else c["size"]
         descs[i].out_features = cfg.embedding_size if composed else out_classes + _spec.BLANK_OFFSET
+        layer = c.get("time_layer")
+        descs[i].time_heads = int(layer.get("num_heads", 1)) if layer else 0
+        descs[i].time_positional = int(bool(layer.get("positional_embeddings", False))) if layer else 0
         deps = c["dependencies"]
         if len(deps) > _lib.AMX_MAX_DEPS:
             raise ValueError("too many dependencies")

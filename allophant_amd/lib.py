@@ -9,7 +9,7 @@ import ctypes as C
 import os
 from typing import Optional
 
-AMX_ABI_VERSION = 1
+AMX_ABI_VERSION = 2
 AMX_MAX_CONV = 8
 AMX_MAX_DEPS = 64
 AMX_NAME_LEN = 48
@@ -48,7 +48,7 @@ class AmxConfig(C.Structure):
 class AmxClassDesc(C.Structure):
     _fields_ = [
         ("name", C.c_char * AMX_NAME_LEN), ("size", C.c_int32), ("out_features", C.c_int32), ("n_deps", C.c_int32),
-        ("deps", C.c_int32 * AMX_MAX_DEPS),
+        ("deps", C.c_int32 * AMX_MAX_DEPS), ("time_heads", C.c_int32), ("time_positional", C.c_int32),
     ]
 
 

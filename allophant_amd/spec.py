@@ -175,6 +175,20 @@ def validate(spec: Dict[str, Any]) -> None:
                 raise ValueError(f"unknown dependency {d!r}")
     if not uses_output:
         raise ValueError(f"At least one of the input layers requires {OUTPUT!r} as a dependency")
+    for c in spec["classes"]:
+        layer = c.get("time_layer")
+        if layer:
+            # `time_layer` = MultiheadAttentionConfig(num_heads, positional_embeddings) (config.py:596-610): the classifier
+            # becomes Linear -> LayerNorm -> (+ sinusoidal positions) -> nn.MultiheadAttention (acoustic_model.py:237-268)
+            heads = int(layer.get("num_heads", 1))
+            if c["name"] == PHONEME and spec.get("embedding_size"):
+                width = int(spec["embedding_size"])
+            elif c["name"] == PHONEME and spec.get("allophone_layer"):
+                width = int(spec.get("shared_phones", c["size"])) + BLANK_OFFSET
+            else:
+                width = int(c["size"]) + BLANK_OFFSET
+            if heads < 1 or width % heads:
+                raise ValueError("embed_dim must be divisible by num_heads")  # nn.MultiheadAttention's own assertion
     evaluation_order(spec["classes"])
     if spec["hidden"] % spec["heads"] != 0:
         raise ValueError("hidden must be divisible by heads")

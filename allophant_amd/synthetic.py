@@ -98,8 +98,20 @@ def make_state_dict(spec: Dict[str, Any], seed: int = 0, include_unused: bool = 
         # with an allophone layer the classifier predicts the shared phone inventory (acoustic_model.py:389-397)
         classes_out = spec.get("shared_phones", node["size"]) if allophone else node["size"]
         n_out = E if composed else classes_out + _spec.BLANK_OFFSET
-        put(p + "_time_distributed_layer.weight", (n_out, n_in), 2.0 / math.sqrt(n_in))
-        put(p + "_time_distributed_layer.bias", (n_out,), 0.1)
+        if node.get("time_layer"):
+            # ProjectingMultiheadAttention (acoustic_model.py:237-253); key names of SURVEY.md Appendix B
+            t = p + "_time_distributed_layer."
+            put(t + "input_projection.weight", (n_out, n_in), 2.0 / math.sqrt(n_in))
+            put(t + "input_projection.bias", (n_out,), 0.1)
+            put(t + "layer_norm.weight", (n_out,), 0.1, 1.0)
+            put(t + "layer_norm.bias", (n_out,), 0.1)
+            put(t + "attention.in_proj_weight", (3 * n_out, n_out), 1.5 / math.sqrt(n_out))
+            put(t + "attention.in_proj_bias", (3 * n_out,), 0.1)
+            put(t + "attention.out_proj.weight", (n_out, n_out), 1.5 / math.sqrt(n_out))
+            put(t + "attention.out_proj.bias", (n_out,), 0.1)
+        else:
+            put(p + "_time_distributed_layer.weight", (n_out, n_in), 2.0 / math.sqrt(n_in))
+            put(p + "_time_distributed_layer.bias", (n_out,), 0.1)
         if composed:
             rows = 1 + sum(spec["composition_categories"])
             put(p + "_composition_layer._attribute_embeddings.weight", (rows, E), 0.6)

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define AMX_ABI_VERSION 1
+#define AMX_ABI_VERSION 2
 
 #define AMX_MAX_CONV 8
 #define AMX_MAX_DEPS 64
@@ -95,6 +95,11 @@ typedef struct amx_class_desc {
     int32_t out_features;           /* rows of `_time_distributed_layer.weight` (size+1, or embedding_size) */
     int32_t n_deps;
     int32_t deps[AMX_MAX_DEPS];     /* >= 0: index of another class; AMX_DEP_OUTPUT; AMX_DEP_OUTPUT_LAYER(i) */
+    /* `time_layer` = MultiheadAttentionConfig (allophant/config.py:596-610): 0 = plain nn.Linear; > 0 = the classifier is a
+     * ProjectingMultiheadAttention (acoustic_model.py:237-268): Linear -> LayerNorm -> (+ sinusoidal positions) ->
+     * nn.MultiheadAttention(out_features, time_heads) over time with the key-padding mask of the frame lengths */
+    int32_t time_heads;
+    int32_t time_positional;        /* add SinusoidalPositionEmbeddings (acoustic_model.py:34-69) */
 } amx_class_desc;
 
 /* One tensor of `Allophant.state_dict()` (= `Checkpoint.model_state`, estimator.py:216), host fp32, reference key

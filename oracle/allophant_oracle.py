@@ -211,9 +211,43 @@ def composed_embeddings(embedding: Tensor, tfi: Tensor, offsets: Tensor) -> Tens
     return torch.cat((blank, phones)).T
 
 
+def sinusoidal_positions(positions: int, size: int) -> Tensor:
+    """SinusoidalPositionEmbeddings.get_positions (acoustic_model.py:34-69): base_k = exp(-2k ln(1e4) / size) repeated
+    for the (sin, cos) pair; even columns sin, odd columns cos."""
+    component = torch.exp(torch.arange(0, size, 2, dtype=torch.float) * -(math.log(10000) / size))
+    bases = torch.stack([component] * 2, 1).view(-1)
+    pe = torch.arange(positions, dtype=torch.float).unsqueeze(1) * bases
+    pe[:, 0::2] = torch.sin(pe[:, 0::2])
+    pe[:, 1::2] = torch.cos(pe[:, 1::2])
+    return pe.view(positions, -1)
+
+
+def time_layer_forward(u: Tensor, frame_lengths: Tensor, state: Dict[str, Tensor], prefix: str, heads: int,
+                       positional: bool) -> Tensor:
+    """ProjectingMultiheadAttention.forward (acoustic_model.py:255-268) on time-major ``u`` [T, N, in]: Linear ->
+    LayerNorm(eps 1e-5) -> (+ positions) -> nn.MultiheadAttention(C, heads) over time with the key-padding mask
+    ``mask_sequence(lengths, inverse=True)``; dropout is the identity in eval mode."""
+    x = F.linear(u, state[prefix + "input_projection.weight"], state[prefix + "input_projection.bias"])
+    x = F.layer_norm(x, (x.shape[-1],), state[prefix + "layer_norm.weight"], state[prefix + "layer_norm.bias"], 1e-5)
+    T, N, C = x.shape
+    if positional:
+        x = x + sinusoidal_positions(T, C).unsqueeze(1)
+    qkv = F.linear(x, state[prefix + "attention.in_proj_weight"], state[prefix + "attention.in_proj_bias"])
+    q, k, v = qkv.split(C, -1)
+    dh = C // heads
+    # [N, heads, T, dh]
+    q, k, v = (t.reshape(T, N, heads, dh).permute(1, 2, 0, 3) for t in (q, k, v))
+    scores = (q / math.sqrt(dh)) @ k.transpose(-1, -2)
+    key_mask = torch.arange(T).unsqueeze(0) >= frame_lengths.unsqueeze(1)  # True = padded key
+    scores = scores.masked_fill(key_mask[:, None, None, :], float("-inf"))
+    o = torch.softmax(scores, -1) @ v  # [N, heads, T, dh]
+    o = o.permute(2, 0, 1, 3).reshape(T, N, C)
+    return F.linear(o, state[prefix + "attention.out_proj.weight"], state[prefix + "attention.out_proj.bias"])
+
+
 def projection_forward(
     hidden_states: List[Tensor], state: Dict[str, Tensor], spec: Dict[str, Any], tfi: Optional[Tensor],
-    category_offsets: Optional[Tensor] = None,
+    category_offsets: Optional[Tensor] = None, frame_lengths: Optional[Tensor] = None,
 ) -> Dict[str, Tensor]:
     """HierarchicalProjection.forward in predict mode on time-major inputs ([T,N,D] each); returns raw logits."""
     outputs: Dict[str, Tensor] = {f"{OUTPUT}_{i}": h for i, h in enumerate(hidden_states)}
@@ -236,7 +270,14 @@ def projection_forward(
                     parts.append(torch.softmax(logits, -1))
             u = torch.cat(parts, -1)
         p = f"{_PROJ}{name}."
-        y = F.linear(u, state[p + "_time_distributed_layer.weight"], state[p + "_time_distributed_layer.bias"])
+        layer = node.get("time_layer")
+        if layer:
+            if frame_lengths is None:
+                raise ValueError("time-layer classifiers need the frame lengths (key-padding mask)")
+            y = time_layer_forward(u, frame_lengths, state, p + "_time_distributed_layer.", int(layer.get("num_heads", 1)),
+                                   bool(layer.get("positional_embeddings", False)))
+        else:
+            y = F.linear(u, state[p + "_time_distributed_layer.weight"], state[p + "_time_distributed_layer.bias"])
         emb_key = p + "_composition_layer._attribute_embeddings.weight"
         if emb_key in state:
             if tfi is None:
@@ -262,7 +303,7 @@ def predict(
     with torch.inference_mode():
         hidden, frame_lengths, inter = wav2vec2_hidden_states(audio, lengths, state, spec, keep_intermediates)
         time_major = [h.transpose(0, 1) for h in hidden]
-        logits = projection_forward(time_major, state, spec, tfi, category_offsets)
+        logits = projection_forward(time_major, state, spec, tfi, category_offsets, frame_lengths)
         if log_probabilities:
             logits = {k: F.log_softmax(v, -1) for k, v in logits.items()}
         if keep_intermediates:

@@ -219,7 +219,7 @@ def integer_goldens():
 
 def main():
     torch.set_num_threads(8)
-    which = set(sys.argv[1:]) or {"g1", "g2", "g2b", "g3", "g4", "g5"}
+    which = set(sys.argv[1:]) or {"g1", "g2", "g2b", "g3", "g4", "g5", "g8"}
     tiny = S.tiny_encoder(2)
     if "g4" in which:
         integer_goldens()
@@ -251,6 +251,21 @@ def main():
         # baseline schema: single non-composed phoneme head (BASELINE config 1 plumbing), tiny shape
         spec = S.baseline_spec(S.tiny_encoder(2), phonemes=10)
         run_case("g5_tiny_baseline", spec, n=1, length=4800, ragged=False, inventory_phones=0, seed=5, store_weights=False)
+    if "g8" in which:
+        # G8: time-layer classifiers (ProjectingMultiheadAttention, acoustic_model.py:237-268): `long` = 3 values + blank
+        # -> embed 4, 2 heads, sinusoidal positions, on cat(softmax(syllabic), OUTPUT); `nasal` = embed 3, 1 head, no
+        # positions, straight on OUTPUT; the composed phoneme head depends on both (hierarchical), ragged batch
+        enc = S.tiny_encoder(2)
+        spec = S.multitask_spec(enc, ["syllabic", "long", "nasal"], embedding_size=16, train_phonemes=9, n_features=5)
+        spec["classes"] = [
+            {"name": "syllabic", "size": 3, "dependencies": ["OUTPUT"]},
+            {"name": "long", "size": 3, "dependencies": ["syllabic", "OUTPUT"],
+             "time_layer": {"num_heads": 2, "positional_embeddings": True}},
+            {"name": "nasal", "size": 2, "dependencies": ["OUTPUT"],
+             "time_layer": {"num_heads": 1, "positional_embeddings": False}},
+            {"name": "phoneme", "size": 9, "dependencies": ["OUTPUT", "long", "nasal"]},
+        ]
+        run_case("g8_tiny_time_layer", spec, n=3, length=5200, ragged=True, inventory_phones=8, seed=8, store_weights=False)
     if "g3" in which:
         # G3: full XLS-R shape, procedural weights (seed 0), 2 x 3 s ragged; sub-sampled tensors only
         spec = S.multitask_spec(S.xlsr_300m_encoder(), allophone_layer=True)

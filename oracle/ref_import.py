@@ -252,8 +252,16 @@ def build_reference_estimator(spec: Dict[str, Any], train_feature_table=None):
     # it would make from `Allophant.from_config` so that state_dict aliasing matches.
     from allophant.network.acoustic_model import _highest_specific_output_layer
 
+    from allophant.config import MultiheadAttentionConfig
+
+    def time_config(c):
+        layer = c.get("time_layer")
+        if not layer:
+            return None
+        return MultiheadAttentionConfig(int(layer.get("num_heads", 1)), bool(layer.get("positional_embeddings", False)))
+
     nodes = [
-        AttributeNode(c["name"], c["size"], None, list(c["dependencies"])) for c in spec["classes"]
+        AttributeNode(c["name"], c["size"], time_config(c), list(c["dependencies"])) for c in spec["classes"]
     ]
     graph = AttributeGraph(nodes)
     highest = _highest_specific_output_layer(graph)
@@ -263,7 +271,7 @@ def build_reference_estimator(spec: Dict[str, Any], train_feature_table=None):
     composition = spec.get("embedding_size")
     allophone_layer = bool(spec.get("allophone_layer", False))
     projection = ProjectionConfig(
-        classes=[ProjectionEntryConfig(c["name"], list(c["dependencies"])) for c in spec["classes"]],
+        classes=[ProjectionEntryConfig(c["name"], list(c["dependencies"]), time_config(c)) for c in spec["classes"]],
         phoneme_layer=PhonemeLayerType.ALLOPHONES if allophone_layer else PhonemeLayerType.SHARED,
         dependency_blanks=bool(spec.get("dependency_blanks", True)),
         embedding_composition=EmbeddingCompositionConfig(composition) if composition else None,

@@ -22,7 +22,8 @@ from golden_util import GOLDEN_DIR, Golden, max_abs_valid_bm, max_abs_valid_tm
 
 pytestmark = pytest.mark.gpu
 
-TINY = ["g1_tiny_multitask", "g2_tiny_hierarchical", "g2b_tiny_hierarchical_blanks", "g5_tiny_baseline"]
+TINY = ["g1_tiny_multitask", "g2_tiny_hierarchical", "g2b_tiny_hierarchical_blanks", "g5_tiny_baseline",
+        "g8_tiny_time_layer"]  # g8: time-layer (ProjectingMultiheadAttention) classifiers, with and without positions
 GATE = 1e-3
 LOOSE = {"f16": 6e-2, "bf16": 5e-1}
 
@@ -303,6 +304,33 @@ def test_xlsr_shape_large_batch_against_oracle(amd):
         for i, (tokens, timesteps, _score) in enumerate(hyps):
             assert torch.equal(decoded[k][i][0].tokens, tokens) and torch.equal(decoded[k][i][0].timesteps, timesteps), (k, i)
     est.close()
+
+
+@pytest.mark.parametrize("embedding,heads", [(160, 1), (16, 4)])
+def test_time_layer_heads_against_oracle(amd, embedding, heads):
+    """Time-layer classifiers beyond the golden case: head_dim 2 (several key groups per wave), head_dim 160 (> 64: the
+    d loop), a composed phoneme head behind a time layer, a time-layer class feeding another one, ragged key masks over
+    149 frames -- against the CPU oracle (whose time layer is pinned to the reference by golden g8)."""
+    from oracle import allophant_oracle as O
+
+    spec = S.hierarchical_spec(S.tiny_encoder(2), ["syllabic", "long", "nasal"], embedding_size=embedding, train_phonemes=12,
+                               n_features=6)
+    by_name = {c["name"]: c for c in spec["classes"]}
+    by_name["syllabic"].update(size=5, time_layer={"num_heads": 3, "positional_embeddings": True})
+    by_name["long"].update(dependencies=["syllabic", S.OUTPUT], time_layer={"num_heads": 1, "positional_embeddings": False})
+    by_name[S.PHONEME]["time_layer"] = {"num_heads": heads, "positional_embeddings": True}
+    S.validate(spec)
+    state = synthetic.make_state_dict(spec, seed=21)
+    tfi = synthetic.make_inventory(spec, 9, seed=5)
+    audio, lengths = synthetic.make_audio(5, 48000, seed=77, ragged=True)
+    ref, ref_len = O.predict(audio, lengths, state, spec, tfi, synthetic.category_offsets(spec))
+    for precision in ("f16x3", "bf16x3"):
+        est = amd.Estimator(spec, state, "cuda:0", precision)
+        pred = est.predict(amd.Batch(audio.cuda(), lengths, torch.zeros(5, dtype=torch.long)), tfi)
+        assert list(pred.outputs) == list(ref) and torch.equal(pred.lengths.cpu(), ref_len)
+        worst = max(max_abs_valid_tm(pred.outputs[k].cpu(), ref[k], ref_len) for k in ref)
+        assert worst < GATE, (precision, worst)
+        est.close()
 
 
 def test_full_size_properties(amd):

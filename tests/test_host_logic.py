@@ -24,7 +24,7 @@ def test_library_loads_and_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     # sizes implied by include/allophant_amx.h (all members are 4-byte aligned scalars / arrays)
     assert C.sizeof(lib.AmxConfig) == 4 * (3 + 8 + 8 + 6 + 1 + 5)
-    assert C.sizeof(lib.AmxClassDesc) == 48 + 4 * 3 + 4 * 64
+    assert C.sizeof(lib.AmxClassDesc) == 48 + 4 * 3 + 4 * 64 + 4 * 2  # + time_heads, time_positional (ABI 2)
     assert C.sizeof(lib.AmxOutputDesc) == 48 + 4 + 4 + 8  # int32 + padding + int64
     assert C.sizeof(lib.AmxTensor) == 24
 
@@ -126,6 +126,31 @@ def test_checkpoint_schema_round_trip(tmp_path):
     # a real-model checkpoint (no encoder override) resolves to the XLS-R-300m shape
     plain = checkpoint.make_checkpoint(S.baseline_spec(S.xlsr_300m_encoder(), 40), {}, synthetic_encoder=False)
     assert checkpoint.spec_from_checkpoint(plain)["hidden"] == 1024
+
+
+def test_time_layer_classifiers_round_trip_and_struct_fields():
+    """`time_layer` (MultiheadAttentionConfig, config.py:596-610) survives checkpoint write/read, reaches the C ABI
+    structs, and num_heads must divide the classifier width like nn.MultiheadAttention asserts."""
+    from golden_util import Golden
+
+    spec = Golden("g8_tiny_time_layer").spec
+    layers = {c["name"]: c.get("time_layer") for c in spec["classes"]}
+    assert layers["long"] == {"num_heads": 2, "positional_embeddings": True} and layers["syllabic"] is None
+    sd = synthetic.make_state_dict(spec, seed=8)
+    prefix = "_projection._layers.long._time_distributed_layer."
+    for leaf in ("input_projection.weight", "layer_norm.bias", "attention.in_proj_weight", "attention.out_proj.bias"):
+        assert prefix + leaf in sd  # module tree of ProjectingMultiheadAttention (acoustic_model.py:237-253)
+    restored = checkpoint.spec_from_checkpoint(checkpoint.make_checkpoint(spec, sd, synthetic_encoder=True))
+    assert restored["classes"] == spec["classes"]
+    _, descs = _spec_to_structs(restored, "f16x3")
+    by_name = {d.name.decode(): d for d in descs}
+    assert (by_name["long"].time_heads, by_name["long"].time_positional) == (2, 1)
+    assert (by_name["nasal"].time_heads, by_name["nasal"].time_positional) == (1, 0)
+    assert by_name["syllabic"].time_heads == 0
+    bad = S.multitask_spec(S.tiny_encoder(1), ["long"], embedding_size=0, train_phonemes=5, n_features=3)
+    bad["classes"][0]["time_layer"] = {"num_heads": 5, "positional_embeddings": False}
+    with pytest.raises(ValueError, match="divisible"):
+        S.validate(bad)
 
 
 def test_batch_and_predictions_containers():

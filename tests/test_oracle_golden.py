@@ -14,7 +14,8 @@ from golden_util import GOLDEN_DIR, Golden, max_abs_valid_bm, max_abs_valid_tm
 from oracle import allophant_oracle as O
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TINY = ["g1_tiny_multitask", "g2_tiny_hierarchical", "g2b_tiny_hierarchical_blanks", "g5_tiny_baseline"]
+TINY = ["g1_tiny_multitask", "g2_tiny_hierarchical", "g2b_tiny_hierarchical_blanks", "g5_tiny_baseline",
+        "g8_tiny_time_layer"]  # g8: time-layer (ProjectingMultiheadAttention) classifiers, with and without positions
 
 
 @pytest.mark.parametrize("name", TINY)
