@@ -779,6 +779,17 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     const int Tpad = T + c.pos_kernel;
     const int64_t rows1 = (int64_t)N * Ts[1], rows2 = (int64_t)N * Ts[2];
 #define WS(name, bytes, ptr) do { if ((rc = ws_get(h, name, (size_t)(bytes), &ptr))) return rc; } while (0)
+    // split-K workspace (fp32 partial slabs of products too small to fill the chip; see launch_gemm): the partials of one
+    // product never exceed CUs x 256 x 256 floats
+    void* splitk = nullptr;
+    constexpr size_t SPLITK_BYTES = (size_t)72 << 20;
+    static const bool no_splitk = getenv("AMX_NO_SPLITK") && atoi(getenv("AMX_NO_SPLITK")) != 0;  // developer A/B switch
+    if (!no_splitk) WS("splitk", SPLITK_BYTES, splitk);
+    auto run_gemm = [&](int precision, GemmParams& g, hipStream_t stream) {
+        g.splitk_ws = (float*)splitk;
+        g.splitk_ws_elems = splitk ? (int64_t)(SPLITK_BYTES / 4) : 0;
+        launch_gemm(precision, g, stream);
+    };
     WS("len", (size_t)N * 8, d_len);
     WS("frames", (size_t)N * 4, d_frames);
     WS("partial", (size_t)N * 64 * 3 * 8, d_partial);
@@ -862,14 +873,14 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             // AMX_NO_FUSED_CONV_LN=1: developer A/B switch (separate fp32 GEMM output + row kernel)
             const char* no_fuse = getenv("AMX_NO_FUSED_CONV_LN");
             if (!(no_fuse && no_fuse[0] == '1') && gemm_fuses_ln(prec, f)) {
-                { Timed t_(h, AMX_KC_GEMM_PP); launch_gemm(prec, f, s); }
+                { Timed t_(h, AMX_KC_GEMM_PP); run_gemm(prec, f, s); }
                 std::swap(cur, other);
                 cur_plane = out_plane;
                 continue;
             }
         }
         g.out_f32 = (float*)preln; g.ldo = C;
-        { Timed t_(h, gemm_class(prec, g)); launch_gemm(prec, g, s); }
+        { Timed t_(h, gemm_class(prec, g)); run_gemm(prec, g, s); }
         if (!last) {
             { Timed t_(h, AMX_KC_ROWNORM); launch_rownorm(prec, (const float*)preln, C, rows_out, C, h->conv_g[i], h->conv_be[i], 1, nullptr, nullptr, 1e-5f,
                            0.f, other, out_plane, C, nullptr, 0, s); }
@@ -895,7 +906,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         g.scale = 1.f; g.bias = h->fp_bias;
         g.row_len = (const int*)d_frames; g.rows_T = T;
         g.out_f32 = (float*)hbuf; g.ldo = D;
-        { Timed t_(h, gemm_class(prec, g)); launch_gemm(prec, g, s); }
+        { Timed t_(h, gemm_class(prec, g)); run_gemm(prec, g, s); }
     }
     // ---- positional conv embedding: h += GELU(grouped conv(h)) ----
     {
@@ -927,7 +938,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             g.mode = 1; g.q = qb; g.k = kb; g.v = vtb;
             g.qk_plane = (int64_t)N * H * Tp * 64;
             g.T = T; g.Tp = Tp; g.H = H; g.dh = 64;
-            { Timed t_(h, gemm_class(prec, g)); launch_gemm(prec, g, s); }
+            { Timed t_(h, gemm_class(prec, g)); run_gemm(prec, g, s); }
         }
         {
             AttnParams a{};
@@ -945,7 +956,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             g.M = (int)M; g.N = D; g.K = D;
             g.scale = 1.f; g.bias = ly.bo;
             g.residual = (const float*)hbuf; g.ldr = D; g.out_f32 = (float*)hbuf; g.ldo = D;
-            { Timed t_(h, gemm_class(prec, g)); launch_gemm(prec, g, s); }
+            { Timed t_(h, gemm_class(prec, g)); run_gemm(prec, g, s); }
         }
         { Timed t_(h, AMX_KC_ROWNORM); launch_rownorm(prec, (const float*)hbuf, D, M, D, ly.ln2_g, ly.ln2_b, 0, nullptr, nullptr, c.eps, 0.f, xp, xp_plane, D,
                        nullptr, 0, s); }
@@ -956,7 +967,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             g.M = (int)M; g.N = F; g.K = D;
             g.scale = 1.f; g.bias = ly.b1; g.act = 1;
             g.out_p = ff; g.out_plane = M * F; g.ldp = F;
-            { Timed t_(h, gemm_class(prec, g)); launch_gemm(prec, g, s); }
+            { Timed t_(h, gemm_class(prec, g)); run_gemm(prec, g, s); }
         }
         {
             GemmParams g{};
@@ -965,7 +976,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             g.M = (int)M; g.N = D; g.K = F;
             g.scale = 1.f; g.bias = ly.b2;
             g.residual = (const float*)hbuf; g.ldr = D; g.out_f32 = (float*)hbuf; g.ldo = D;
-            { Timed t_(h, gemm_class(prec, g)); launch_gemm(prec, g, s); }
+            { Timed t_(h, gemm_class(prec, g)); run_gemm(prec, g, s); }
         }
     }
     { Timed t_(h, AMX_KC_ROWNORM); launch_rownorm(prec, (const float*)hbuf, D, M, D, h->fln_g, h->fln_b, 0, nullptr, nullptr, c.eps, 0.f, xp, xp_plane, D,
@@ -1032,7 +1043,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             // ProjectingMultiheadAttention.forward (acoustic_model.py:255-268)
             const int Co = st.rows, Cp = st.Cpad;
             g.out_f32 = (float*)tl_x; g.ldo = Co;
-            { Timed t_(h, gemm_class(prec, g)); launch_gemm(prec, g, s); }
+            { Timed t_(h, gemm_class(prec, g)); run_gemm(prec, g, s); }
             { Timed t_(h, AMX_KC_OTHER); launch_time_ln_pe(prec, (const float*)tl_x, M, Co, T, st.tl_g, st.tl_b, 1e-5f, st.tl_pe, tl_p,
                               M * Cp, Cp, s); }
             GemmParams gi{};
@@ -1041,7 +1052,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             gi.M = (int)M; gi.N = 3 * Co; gi.K = Cp;
             gi.scale = 1.f; gi.bias = st.tl_bin;
             gi.out_f32 = (float*)tl_qkv; gi.ldo = 3 * Co;
-            { Timed t_(h, gemm_class(prec, gi)); launch_gemm(prec, gi, s); }
+            { Timed t_(h, gemm_class(prec, gi)); run_gemm(prec, gi, s); }
             { Timed t_(h, AMX_KC_OTHER); launch_time_attention(prec, (const float*)tl_qkv, (const int*)d_frames, N, T, Co, st.time_heads,
                                   tl_p, M * Cp, Cp, s); }
             // out_proj lands where the plain linear classifier would have written
@@ -1053,7 +1064,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         }
         if (st.composed) {
             g.out_p = ebuf; g.out_plane = M * E; g.ldp = E;
-            { Timed t_(h, gemm_class(prec, g)); launch_gemm(prec, g, s); }
+            { Timed t_(h, gemm_class(prec, g)); run_gemm(prec, g, s); }
             // logits = (e @ composed) / sqrt(E)   (acoustic_model.py:234)
             GemmParams g2{};
             g2.A = ebuf; g2.a_plane = M * E; g2.lda = E; g2.rows_per_batch = M;
@@ -1061,10 +1072,10 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             g2.M = (int)M; g2.N = h->P1; g2.K = E;
             g2.scale = 1.0f / sqrtf((float)E);
             g2.out_f32 = (float*)logits + h->col[st.classes[0]]; g2.ldo = h->ld_logits;
-            { Timed t_(h, gemm_class(prec, g2)); launch_gemm(prec, g2, s); }
+            { Timed t_(h, gemm_class(prec, g2)); run_gemm(prec, g2, s); }
         } else {
             g.out_f32 = (float*)logits + h->col[st.classes[0]]; g.ldo = h->ld_logits;
-            { Timed t_(h, gemm_class(prec, g)); launch_gemm(prec, g, s); }
+            { Timed t_(h, gemm_class(prec, g)); run_gemm(prec, g, s); }
         }
     }
     { Timed t_(h, AMX_KC_OTHER); launch_logsoftmax_out(h->out_unique_dev, (int)h->out_unique.size(), (const float*)logits, h->ld_logits, N, T,

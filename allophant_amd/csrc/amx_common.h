@@ -137,6 +137,13 @@ struct GemmParams {
     const float* ln_gamma;
     const float* ln_beta;
     float ln_eps;
+    // split-K: products whose tile count cannot fill the chip are cut along K into `splits` chunks; every chunk writes a
+    // raw fp32 partial [M, N] into a slab of `splitk_ws` and a fix-up kernel reduces the slabs (fixed order, so results are
+    // deterministic) and applies the epilogue.  The caller only provides the workspace; launch_gemm decides.
+    float* splitk_ws;
+    int64_t splitk_ws_elems;  // capacity in floats
+    int splits;               // internal (kernel view): number of K chunks, K = chunk length
+    int64_t split_out;        // internal: distance between partial slabs (elements)
     unsigned long long* stamps;  // developer diagnostic (-DAMX_PP_STAMP builds of tools/gemm_bench.hip), else null
 };
 

@@ -9,6 +9,7 @@
 // * A rows may overlap (lda < K): the strided 1-D convolutions of the wav2vec2 feature extractor and the grouped
 //   positional convolution are implicit GEMMs over channels-last activations, no im2col buffer.
 #include "amx_common.h"
+#include <algorithm>
 #include <type_traits>
 
 namespace amx {
@@ -263,6 +264,37 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
     gemm_epilogue<T, NT, MI, NI>(p, z, acc, m0 + wm * TM, n0 + wn * TN, lane);
 }
 
+// Split-K fix-up: sums the `splits` raw fp32 partial slabs [M, N] of a product (slab stride `slab` floats, in slab order,
+// so the result does not depend on scheduling) and runs the shared epilogue on the totals.  A wave owns a 16 x 64 patch.
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void splitk_fixup_kernel(const GemmParams p, const float* __restrict__ ws, int splits,
+                                                           int64_t slab) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m_base = (blockIdx.y * 4 + wave) * 16, n_base = blockIdx.x * 64;
+    if (m_base >= p.M) return;
+    f32x4 acc[4][1];
+    const int m = m_base + (lane & 15);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        acc[ni][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int nb = n_base + ni * 16 + 4 * (lane >> 4);
+        if (m >= p.M || nb >= p.N) continue;
+        const float* src = ws + (int64_t)m * p.N + nb;
+        if ((p.N & 3) == 0) {
+            for (int k = 0; k < splits; ++k) {
+                const float4 v = *(const float4*)(src + k * slab);
+                acc[ni][0][0] += v.x; acc[ni][0][1] += v.y; acc[ni][0][2] += v.z; acc[ni][0][3] += v.w;
+            }
+        } else {
+            for (int k = 0; k < splits; ++k)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (nb + r < p.N) acc[ni][0][r] += src[k * slab + r];
+        }
+    }
+    gemm_epilogue<T, NT, 1, 4>(p, 0, acc, m_base, n_base, lane);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Ping-pong GEMM for the large products (conv layers 1-6, feature projection, QKV / out-proj / FFN, phoneme head):
 //   persistent workgroups (one per CU) walk 256 x 256 output tiles; 8 waves = 2 groups x 4 waves (one wave of each
@@ -325,13 +357,14 @@ __device__ __forceinline__ void pp_stage_round(float* es, f32x4 (&acc)[4][8], in
 // fp32 output (+ bias, + residual): a lane owns 4 consecutive columns; 16 lanes cover a 256-byte row segment.
 // All loads of a 32-row round are issued before the first use, all stores after: no wait inside the round.
 template <bool RES>
-__device__ __forceinline__ void pp_epilogue_f32(const GemmParams& p, f32x4 (&acc)[4][8], float* es, int lane, int mw, int nw) {
+__device__ __forceinline__ void pp_epilogue_f32(const GemmParams& p, f32x4 (&acc)[4][8], float* es, int lane, int mw, int nw,
+                                                float* out_f32) {
     const int ch = lane & 15, rq = (lane >> 4) * 8;  // rows rq + i: every 16-lane group reads rows of equal row & 7
     const int n = nw + ch * 4;
     const float scale = p.scale;
     float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias) b4 = *(const float4*)(p.bias + n);
-    float* optr = p.out_f32 + (int64_t)(mw + rq) * p.ldo + n;
+    float* optr = out_f32 + (int64_t)(mw + rq) * p.ldo + n;
     const float* rptr = RES ? p.residual + (int64_t)(mw + rq) * p.ldr + n : nullptr;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -423,7 +456,8 @@ __device__ __forceinline__ void pp_epilogue_p16(const GemmParams& p, f32x4 (&acc
 
 // edge blocks (M / N tails), row masks, combined fp32 + plane outputs: every feature, runtime flags
 template <typename T, int NT>
-__device__ __forceinline__ void pp_epilogue_generic(const GemmParams& p, f32x4 (&acc)[4][8], float* es, int lane, int mw, int nw) {
+__device__ __forceinline__ void pp_epilogue_generic(const GemmParams& p, f32x4 (&acc)[4][8], float* es, int lane, int mw, int nw,
+                                                    float* out_f32) {
     typedef typename Vec4<T>::type V4;
     const int D = p.H * p.dh;
     const float scale = p.scale;
@@ -481,7 +515,7 @@ __device__ __forceinline__ void pp_epilogue_generic(const GemmParams& p, f32x4 (
                         *(V4*)(dst + p.qk_plane) = lv;
                     }
                 } else {
-                    if (p.out_f32) *(float4*)(p.out_f32 + (int64_t)m * p.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (out_f32) *(float4*)(out_f32 + (int64_t)m * p.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
                     if (p.out_p) {
                         T hi[4], lo[4];
 #pragma unroll
@@ -515,7 +549,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wc = wave & 3;
     const int ntn = (p.N + pp::BN - 1) / pp::BN, ntm = (p.M + pp::BM - 1) / pp::BM;
-    const int total = ntn * ntm;
+    const int tiles = ntn * ntm;
+    // split-K (p.splits > 1, set by launch_gemm for products with too few tiles to fill the chip): a work unit is
+    // (tile, K chunk of p.K elements); chunk ks reads A / W columns [ks * p.K, (ks + 1) * p.K) and writes its raw fp32
+    // partial tile to slab ks of the workspace p.out_f32 points to (the fix-up kernel reduces and runs the epilogue)
+    const int total = tiles * p.splits;
 
     // ---- fragment read offsets (bytes inside a slot) ----
     const int rd_chunk = ((lane >> 4) ^ ((lane >> 2) & 2)) << 4;
@@ -525,10 +563,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 
     // ---- per-tile DMA state: this wave fills pieces 2*wave, 2*wave+1 (16 rows x 64 B each) of the A part and of the
     // W part of a slot; addresses are (wave-uniform tile base in an SGPR buffer descriptor) + (32-bit per-lane offset)
-    int m0 = 0, n0 = 0;
+    int m0 = 0, n0 = 0, ks = 0;
     __amdgpu_buffer_rsrc_t a_rsrc, w_rsrc;
     uint32_t a_off[2], w_off[2];
-    auto setup_tile = [&](int i) {
+    auto setup_tile = [&](int unit) {
+        ks = unit / tiles;
+        const int i = unit - ks * tiles;
+        const int total = tiles;
         // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (private 4 MiB L2 each), so the tile
         // sequence numbers that share an XCD (equal i % 8) are given one contiguous chunk of a grouped tile sequence in
         // which the 32 co-resident tiles of an XCD form an 8 (M) x 4 (N) rectangle.  Pure speed: any placement gives
@@ -546,8 +587,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         const int m0c = m0 < p.M ? m0 : p.M - 1, n0c = n0 < p.N ? n0 : p.N - 1;
         const int64_t b0 = m0c / p.rows_per_batch;
         const int64_t a_tile = b0 * p.a_batch_stride + (m0c - b0 * p.rows_per_batch) * p.lda;  // element offset of row m0
-        a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.A + a_tile), 0, -1, 0x00020000);
-        w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.W + (int64_t)n0c * p.ldw), 0, -1, 0x00020000);
+        const int64_t k_first = (int64_t)ks * p.K;
+        a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.A + a_tile + k_first), 0, -1, 0x00020000);
+        w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.W + (int64_t)n0c * p.ldw + k_first), 0, -1, 0x00020000);
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             const int row = (wave * 2 + jj) * 16 + ((tid & 63) >> 2);
@@ -732,6 +774,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 
         // ---- next tile: set up its DMA state and start its first two sub-steps under this tile's epilogue ----
         const int mw = m0 + grp * 128, nw = n0 + wc * 64;
+        float* out_f32 = p.out_f32 ? p.out_f32 + (int64_t)ks * p.split_out : nullptr;
         const int next = it + gridDim.x;
         const bool has_next = next < total;
         if (has_next) {
@@ -754,8 +797,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
                         done = true;
                     }
                 } else if (p.out_f32 && !p.out_p && p.act == 0) {
-                    if (p.residual) pp_epilogue_f32<true>(p, acc, es, lane, mw, nw);
-                    else pp_epilogue_f32<false>(p, acc, es, lane, mw, nw);
+                    if (p.residual) pp_epilogue_f32<true>(p, acc, es, lane, mw, nw, out_f32);
+                    else pp_epilogue_f32<false>(p, acc, es, lane, mw, nw, out_f32);
                     done = true;
                 } else if (p.out_p && !p.out_f32 && !p.residual && p.ldp % 8 == 0 && p.out_plane % 8 == 0 && !((uintptr_t)p.out_p & 15)) {
                     if (p.act == 1) pp_epilogue_p16<T, NT, true, false>(p, acc, es, lane, mw, nw);
@@ -763,7 +806,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
                     done = true;
                 }
             }
-            if (!done) pp_epilogue_generic<T, NT>(p, acc, es, lane, mw, nw);
+            if (!done) pp_epilogue_generic<T, NT>(p, acc, es, lane, mw, nw, out_f32);
         }
 #else
 #pragma unroll
@@ -1151,15 +1194,7 @@ bool pp_eligible(int NT, const GemmParams& p) {
     return true;
 }
 
-template <typename T, int NT>
-bool launch_gemm_pp(const GemmParams& p, hipStream_t stream) {
-    if (!pp_eligible(NT, p)) return false;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, pp::LDS_BYTES);
-        attr_set = true;
-    }
-    const int tiles = ((p.N + pp::BN - 1) / pp::BN) * ((p.M + pp::BM - 1) / pp::BM);
+int device_cus() {
     static int cus = 0;
     if (!cus) {
         int dev = 0;
@@ -1169,27 +1204,100 @@ bool launch_gemm_pp(const GemmParams& p, hipStream_t stream) {
         cus -= cus % 8;  // the tile order assumes sequence numbers i and i + grid share an XCD
         if (cus < 8) cus = 8;
     }
-    dim3 grid(tiles < cus ? tiles : cus, 1, 1);  // persistent: one 128-KiB-LDS workgroup per CU
-    hipLaunchKernelGGL((gemm_pp_kernel<T, NT>), grid, dim3(512), pp::LDS_BYTES, stream, p);
+    return cus;
+}
+
+// Number of K chunks for a product of `tiles` output tiles: 1 when no workspace was given or the tiles alone occupy more
+// than `max_tiles` CUs; otherwise the largest divisor of K / granule that neither over-subscribes the chip, nor makes chunks
+// shorter than `min_chunk`, nor overflows the workspace.  (Thresholds from tools/gemm_bench `small`: the fix-up launch and
+// the partial slabs cost 10-15 us, so a split only pays when it removes more main-loop time than that.)
+int choose_splits(const GemmParams& p, int tiles, int max_tiles, int granule, int min_chunk) {
+    if (!p.splitk_ws || p.K % granule || p.K < 2 * min_chunk || tiles > max_tiles) return 1;
+    int64_t smax = device_cus() / tiles;
+    smax = std::min<int64_t>(smax, p.K / min_chunk);
+    smax = std::min<int64_t>(smax, p.splitk_ws_elems / ((int64_t)p.M * p.N));
+    smax = std::min<int64_t>(smax, 32);
+    const int n_g = p.K / granule;
+    int best = 1;
+    for (int sp = 2; sp <= smax; ++sp)
+        if (n_g % sp == 0) best = sp;
+    return best;
+}
+
+// the kernel-side view of one K chunk: raw fp32 partials into the workspace, no epilogue features
+GemmParams split_view(const GemmParams& p, int splits) {
+    GemmParams q = p;
+    q.K = p.K / splits;
+    q.splits = splits;
+    q.split_out = (int64_t)p.M * p.N;
+    q.out_f32 = p.splitk_ws;
+    q.ldo = p.N;
+    q.out_p = nullptr;
+    q.bias = nullptr;
+    q.scale = 1.f;
+    q.act = 0;
+    q.residual = nullptr;
+    q.row_len = nullptr;
+    q.mode = 0;
+    q.ln_gamma = q.ln_beta = nullptr;
+    q.vec_ok = (p.N % 4 == 0) ? 1 : 0;
+    return q;
+}
+
+template <typename T, int NT>
+void launch_fixup(const GemmParams& p, int splits, hipStream_t stream) {
+    dim3 grid((p.N + 63) / 64, (p.M + 63) / 64);
+    hipLaunchKernelGGL((splitk_fixup_kernel<T, NT>), grid, dim3(256), 0, stream, p, (const float*)p.splitk_ws, splits,
+                       (int64_t)p.M * p.N);
+}
+
+template <typename T, int NT>
+bool launch_gemm_pp(const GemmParams& p, hipStream_t stream) {
+    if (!pp_eligible(NT, p)) return false;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, pp::LDS_BYTES);
+        attr_set = true;
+    }
+    const int tiles = ((p.N + pp::BN - 1) / pp::BN) * ((p.M + pp::BM - 1) / pp::BM);
+    const int cus = device_cus();
+    // main-loop length of a tile in MFMA segments: long loops (K = 4096, or 1536 with split planes) are cut when half the
+    // chip would idle, 1024-deep split-plane loops only when three quarters would; 1024-deep single-plane loops never
+    const int weight = p.K * (NT > 1 ? 3 : 1);
+    const int max_tiles = weight >= 4096 ? cus / 2 : (weight >= 3072 ? cus / 4 : 0);
+    const int splits = choose_splits(p, tiles, max_tiles, 128, 256);
+    const int units = tiles * splits;
+    dim3 grid(units < cus ? units : cus, 1, 1);  // persistent: one 128-KiB-LDS workgroup per CU
+    if (splits > 1) {
+        hipLaunchKernelGGL((gemm_pp_kernel<T, NT>), grid, dim3(512), pp::LDS_BYTES, stream, split_view(p, splits));
+        launch_fixup<T, NT>(p, splits, stream);
+    } else {
+        hipLaunchKernelGGL((gemm_pp_kernel<T, NT>), grid, dim3(512), pp::LDS_BYTES, stream, p);
+    }
     return true;
 }
 
 template <typename T, int NT>
 void launch_gemm_t(const GemmParams& p, hipStream_t stream) {
-    int zdim = 1;
     if (launch_gemm_pp<T, NT>(p, stream)) return;
     // narrow outputs (grouped pos-conv, small classifier heads) use the 128x64 tile
-    if (p.N <= 64) {
-        constexpr int BM = 128, BN = 64;
-        dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, zdim);
-        size_t lds = (size_t)NT * (BM + BN) * 128;
-        hipLaunchKernelGGL((gemm_kernel<T, NT, BM, BN, 4, 1>), grid, dim3(256), lds, stream, p);
-    } else {
-        constexpr int BM = 128, BN = 128;
-        dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, zdim);
-        size_t lds = (size_t)NT * (BM + BN) * 128;
-        hipLaunchKernelGGL((gemm_kernel<T, NT, BM, BN, 2, 2>), grid, dim3(256), lds, stream, p);
+    const bool narrow = p.N <= 64;
+    const int BM = 128, BN = narrow ? 64 : 128;
+    const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
+    // short products (a single utterance, the late conv layers): the K loop of a tile is latency-bound, so cut it
+    const int splits = choose_splits(p, tiles, device_cus() / 4, BK, 2 * BK);
+    GemmParams q = p;
+    if (splits > 1) {
+        q = split_view(p, splits);
+        q.za = q.zw = q.K;              // grid.z = K chunk: operand pointers advance by the chunk length,
+        q.zout = q.split_out;           // the fp32 output by one slab
+        q.zbias = q.zoutp = 0;
     }
+    dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, splits);
+    const size_t lds = (size_t)NT * (BM + BN) * 128;
+    if (narrow) hipLaunchKernelGGL((gemm_kernel<T, NT, 128, 64, 4, 1>), grid, dim3(256), lds, stream, q);
+    else hipLaunchKernelGGL((gemm_kernel<T, NT, 128, 128, 2, 2>), grid, dim3(256), lds, stream, q);
+    if (splits > 1) launch_fixup<T, NT>(p, splits, stream);
 }
 
 template <typename T, int NT>
@@ -1204,6 +1312,8 @@ void launch_gemm_z(const GemmParams& p, int zdim, hipStream_t stream) {
 
 static GemmParams with_vec_flag(const GemmParams& in) {
     GemmParams p = in;
+    p.splits = 1;
+    p.split_out = 0;
     p.vec_ok = (p.N % 4 == 0) && (!p.out_f32 || (p.ldo % 4 == 0 && p.zout % 4 == 0 && ((uintptr_t)p.out_f32 & 15) == 0)) &&
                (!p.out_p || (p.ldp % 4 == 0 && p.zoutp % 4 == 0 && p.out_plane % 4 == 0 && ((uintptr_t)p.out_p & 7) == 0));
     return p;

@@ -126,7 +126,10 @@ def main():
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
 
-    if world > 1:
+    # AMX_BENCH_FORCE_DIST=1 (developer switch): run the RCCL gather path with a one-rank group, so that the collective
+    # code is exercised on a single-GPU box (launch under torch.distributed.run --nproc-per-node 1)
+    use_dist = world > 1 or os.environ.get("AMX_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         dist.init_process_group("nccl", device_id=device)
 
     from allophant_amd import parallel
@@ -148,7 +151,7 @@ def main():
 
         def step(timing=False):
             pred = est.predict(batch, tfi, True, _timing=timing)
-            if world > 1:
+            if use_dist:
                 # RCCL gather of the per-frame log-probabilities (one flat fp32 block per rank) + frame lengths to rank 0,
                 # which re-assembles `Predictions` of the global batch: [T, n * world, C] per output
                 gathered = parallel.gather_flat_predictions(pred, device, dst=0)
@@ -158,19 +161,19 @@ def main():
 
         for _ in range(warmup):
             step()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         t_tensor = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(t_tensor, op=dist.ReduceOp.MAX)
         elapsed = float(t_tensor.item())
         # instrumented pass: same steps, HIP events on the launch stream around every kernel
@@ -268,7 +271,7 @@ def main():
         else:
             result["cpu_baseline"] = None
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -68,7 +68,14 @@ struct Case {
     float scale;
 };
 
+// variant 0 always gets a split-K workspace (launch_gemm decides whether to use it); variant 1 is the unsplit generic
+// kernel, or -- with g_compare_nosplit -- the same automatic choice without a workspace
+static bool g_compare_nosplit = false;
+static float* g_splitk_ws = nullptr;
+static const int64_t SPLITK_ELEMS = (int64_t)18 << 20;
+
 static double run_case(int prec, const Case& c, bool timing_only, double* us_pp, double* us_gen) {
+    if (!g_splitk_ws) CK(hipMalloc(&g_splitk_ws, SPLITK_ELEMS * 4));
     const int NT = prec_planes(prec);
     const int64_t rows_per_batch = c.conv_rows_per_batch ? c.conv_rows_per_batch : c.M;
     const int64_t lda = c.conv_lda ? c.conv_lda : c.K;
@@ -113,7 +120,8 @@ static double run_case(int prec, const Case& c, bool timing_only, double* us_pp,
             g.mode = 1; g.q = q; g.k = k; g.v = vt; g.qk_plane = qk_el; g.T = T; g.Tp = Tp; g.H = H; g.dh = dh;
             g.row_len = row_len;
         }
-        g_force_generic_gemm = variant == 1;
+        g_force_generic_gemm = variant == 1 && !g_compare_nosplit;
+        if (variant == 0) { g.splitk_ws = g_splitk_ws; g.splitk_ws_elems = SPLITK_ELEMS; }
         launch_gemm(prec, g, 0);
         CK(hipDeviceSynchronize());
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -234,6 +242,29 @@ int main(int argc, char** argv) {
 #endif
     const bool check = argc < 2 || !strcmp(argv[1], "check");
     const bool timing = argc < 2 || !strcmp(argv[1], "time");
+    if (argc > 1 && !strcmp(argv[1], "small")) {
+        // products of short batches (rows = frames of 1 x 3 s, 1 x 10 s, 4 x 10 s, 1 x 60 s): split-K against no split
+        g_compare_nosplit = true;
+        const int rows[] = {149, 499, 1996, 2999, 7984};
+        int precs[] = {PREC_F16X3, PREC_BF16};
+        for (int prec : precs)
+            for (int M : rows) {
+                Case shapes[] = {
+                    {"ffn1 (gelu -> planes)", M, 4096, 1024, 1, 0, 0, 1, 0, 0, 0, 0, 1.f},
+                    {"ffn2 (+res -> f32)", M, 1024, 4096, 0, 1, 0, 0, 1, 0, 0, 0, 1.f},
+                    {"qkv (scatter)", M, 3072, 1024, 0, 0, 0, 0, 0, 1, 0, 0, 1.f},
+                    {"out-proj (+res -> f32)", M, 1024, 1024, 0, 1, 0, 0, 1, 0, 0, 0, 1.f},
+                };
+                for (auto& c : shapes) {
+                    double a = 0, b = 0;
+                    run_case(prec, c, true, &a, &b);
+                    double fl = 2.0 * c.M * c.N * c.K;
+                    printf("SMALL prec=%d %-24s M=%5d N=%d K=%d : split-K %.1f us %.1f TF/s | no split %.1f us %.1f TF/s\n", prec,
+                           c.name, c.M, c.N, c.K, a, fl / a * 1e-6, b, fl / b * 1e-6);
+                }
+            }
+        return 0;
+    }
     if (check) {
         Case cases[] = {
             {"dense gelu->planes, M tail", 1500, 512, 256, 1, 0, 0, 1, 0, 0, 0, 0, 1.0f},
@@ -242,6 +273,14 @@ int main(int argc, char** argv) {
             {"conv-like overlapping rows", 2800, 512, 384, 0, 0, 0, 0, 1, 0, 700, 256, 1.0f},
             {"qkv scatter", 1497, 384, 256, 0, 0, 0, 0, 0, 1, 0, 0, 1.0f},
             {"long K", 1100, 256, 4096, 0, 1, 0, 0, 1, 0, 0, 0, 1.0f},
+            // split-K (few tiles): ping-pong kernel with K chunks, generic kernel with grid.z chunks, + fix-up epilogue
+            {"split pp gelu->planes", 2000, 1024, 1024, 1, 0, 0, 1, 0, 0, 0, 0, 1.0f},
+            {"split pp qkv scatter", 1996, 3072, 1024, 0, 0, 0, 0, 0, 1, 0, 0, 1.0f},
+            {"split pp f32 +res +mask +planes", 1300, 512, 2048, 0, 1, 1, 1, 1, 0, 0, 0, 0.25f},
+            {"split generic f32 +res +mask, N%4", 300, 1022, 1024, 0, 1, 1, 0, 1, 0, 0, 0, 0.5f},
+            {"split generic gelu->planes", 149, 4096, 1024, 1, 0, 0, 1, 0, 0, 0, 0, 1.0f},
+            {"split generic conv-like", 598, 512, 1536, 0, 0, 0, 0, 1, 0, 299, 1024, 1.0f},
+            {"split generic qkv scatter", 499, 3072, 1024, 0, 0, 0, 0, 0, 1, 0, 0, 1.0f},
         };
         int precs[] = {PREC_F16X3, PREC_BF16X3, PREC_F16, PREC_BF16};
         int bad = 0;
