@@ -873,7 +873,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             // AMX_NO_FUSED_CONV_LN=1: developer A/B switch (separate fp32 GEMM output + row kernel)
             const char* no_fuse = getenv("AMX_NO_FUSED_CONV_LN");
             if (!(no_fuse && no_fuse[0] == '1') && gemm_fuses_ln(prec, f)) {
-                { Timed t_(h, AMX_KC_GEMM_PP); run_gemm(prec, f, s); }
+                { Timed t_(h, AMX_KC_GEMM_LN); run_gemm(prec, f, s); }
                 std::swap(cur, other);
                 cur_plane = out_plane;
                 continue;

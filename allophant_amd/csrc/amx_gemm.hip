@@ -281,9 +281,16 @@ __global__ __launch_bounds__(256) void splitk_fixup_kernel(const GemmParams p, c
         if (m >= p.M || nb >= p.N) continue;
         const float* src = ws + (int64_t)m * p.N + nb;
         if ((p.N & 3) == 0) {
-            for (int k = 0; k < splits; ++k) {
-                const float4 v = *(const float4*)(src + k * slab);
-                acc[ni][0][0] += v.x; acc[ni][0][1] += v.y; acc[ni][0][2] += v.z; acc[ni][0][3] += v.w;
+            // eight slab reads in flight per lane (a rolled loop would pay one memory round trip per slab)
+            for (int k0 = 0; k0 < splits; k0 += 8) {
+                float4 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    v[j] = k0 + j < splits ? *(const float4*)(src + (k0 + j) * slab) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    acc[ni][0][0] += v[j].x; acc[ni][0][1] += v[j].y; acc[ni][0][2] += v[j].z; acc[ni][0][3] += v[j].w;
+                }
             }
         } else {
             for (int k = 0; k < splits; ++k)

@@ -17,7 +17,7 @@ AMX_NAME_LEN = 48
 AMX_OK, AMX_EINVAL, AMX_EHIP, AMX_ESTATE, AMX_ENOMEM = 0, -1, -2, -3, -4
 PRECISIONS = {"bf16": 0, "f16": 1, "bf16x3": 2, "f16x3": 3}
 FLAG_HOST_IO, FLAG_RAW_LOGITS, FLAG_KEEP_HIDDEN, FLAG_TIMING = 1, 2, 4, 8
-KERNEL_CLASSES = ["gemm_pp", "gemm_tile", "attention", "rownorm", "conv0", "other"]
+KERNEL_CLASSES = ["gemm_pp", "gemm_tile", "attention", "rownorm", "conv0", "other", "gemm_ln"]
 DEP_OUTPUT = -1
 
 LIB_NAME = "liballophant_amx.so"

@@ -51,8 +51,16 @@ def gemm_flops(spec, n, length, planes):
     T = ts[-1]
     M = n * T
     products = []  # (M, N, K, launches)
+    ln = ln_launches = 0
+    last_conv = len(spec["conv_kernel"]) - 1
     for i in range(1, len(spec["conv_kernel"])):
-        products.append((n * ts[i + 1], C, C * spec["conv_kernel"][i], 1))
+        m, k = n * ts[i + 1], C * spec["conv_kernel"][i]
+        if i < last_conv and C == 512 and m >= 1024 and k % (128 // planes) == 0:
+            # `ln_eligible`: the row-complete 128 x 512 kernel with fused LayerNorm + GELU (conv layers before the last)
+            ln += 2 * m * C * k
+            ln_launches += 1
+        else:
+            products.append((m, C, k, 1))
     products.append((M, D, C, 1))
     for shape in ((3 * D, D), (D, D), (F, D), (D, F)):
         products.append((M, shape[0], shape[1], spec["layers"]))
@@ -70,9 +78,9 @@ def gemm_flops(spec, n, length, planes):
             tile += fl
     tile += 2 * M * D * (D // spec["pos_groups"]) * spec["pos_kernel"]  # grouped positional conv
     attention = spec["layers"] * 4 * M * T * D
-    total = pp + tile + attention + 2 * n * ts[1] * C * spec["conv_kernel"][0]
-    return {"gemm_pp": pp, "gemm_pp_launches": pp_launches, "gemm_tile": tile, "attention": attention, "total": total,
-            "frames_per_utt": T}
+    total = pp + ln + tile + attention + 2 * n * ts[1] * C * spec["conv_kernel"][0]
+    return {"gemm_pp": pp, "gemm_pp_launches": pp_launches, "gemm_ln": ln, "gemm_ln_launches": ln_launches, "gemm_tile": tile,
+            "attention": attention, "total": total, "frames_per_utt": T}
 
 
 def cpu_baseline(spec, state, tfi, n_sample, length):
@@ -192,8 +200,8 @@ def main():
         gemm_ms, gemm_launches = timing["gemm_pp"]
         achieved = fl["gemm_pp"] * steps / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else None
         return fl, frames_per_rank, {
-            "kernel": "gemm_pp_kernel<T16, planes>: persistent 256x256 ping-pong GEMM (conv layers 1-6, feature projection, "
-                      "QKV/out/FFN, phoneme head)",
+            "kernel": "gemm_pp_kernel<T16, planes>: persistent 256x256 ping-pong GEMM (last conv layer, feature projection, "
+                      "QKV / out-proj / FFN of the 24 encoder layers, phoneme head)",
             "bound": "mfma",
             "achieved": achieved,
             "peak": MFMA_PEAK_TFLOPS,
@@ -205,6 +213,11 @@ def main():
             "launches_per_step": gemm_launches // max(1, steps),
             "mfma_issue_factor": 3 if planes == 2 else 1,
             "issued_frac": (3 if planes == 2 else 1) * achieved / MFMA_PEAK_TFLOPS if achieved else None,
+            "conv_ln_gemm": {
+                "kernel": "gemm_ln_kernel<T16, planes>: 128x512 row-complete GEMM + LayerNorm + GELU (conv layers 1-5)",
+                "achieved": fl["gemm_ln"] * steps / (timing["gemm_ln"][0] * 1e-3) / 1e12 if timing["gemm_ln"][0] > 0 else None,
+                "avg_launch_ms": timing["gemm_ln"][0] / timing["gemm_ln"][1] if timing["gemm_ln"][1] else None,
+            },
             "timing": "HIP events around every launch in a second pass of the same K steps (recording them costs ~1.2 ms per "
                       "step, so the timed region that yields `value` runs without them)",
         }

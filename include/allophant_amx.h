@@ -51,13 +51,14 @@ extern "C" {
 #define AMX_FLAG_TIMING 8u       /* bracket every kernel launch with HIP events on the launch stream (amx_timing_fetch) */
 
 /* kernel classes reported by amx_timing_fetch */
-#define AMX_KC_GEMM_PP 0   /* gemm_pp_kernel<T, NT>: 256x256 ping-pong GEMM -- conv 1-6, feature projection, QKV/out/FFN, wide heads */
+#define AMX_KC_GEMM_PP 0   /* gemm_pp_kernel<T, NT>: 256x256 ping-pong GEMM -- conv layer 6, feature projection, QKV/out/FFN, wide heads */
 #define AMX_KC_GEMM_TILE 1 /* gemm_kernel<T, NT, 128, {128,64}>: grouped positional conv, narrow heads, shapes the 256x256 kernel rejects */
 #define AMX_KC_ATTENTION 2
 #define AMX_KC_ROWNORM 3
 #define AMX_KC_CONV0 4
 #define AMX_KC_OTHER 5
-#define AMX_KC_COUNT 6
+#define AMX_KC_GEMM_LN 6   /* gemm_ln_kernel<T, NT>: row-complete 128x512 GEMM with fused LayerNorm + GELU -- conv layers 1-5 */
+#define AMX_KC_COUNT 7
 
 /* dependency codes in amx_class_desc.deps */
 #define AMX_DEP_OUTPUT (-1)                 /* "OUTPUT"   (allophant/config.py:636) */

@@ -242,6 +242,16 @@ int main(int argc, char** argv) {
 #endif
     const bool check = argc < 2 || !strcmp(argv[1], "check");
     const bool timing = argc < 2 || !strcmp(argv[1], "time");
+    if (argc > 5 && !strcmp(argv[1], "one")) {
+        // one shape, for rocprofv3 --kernel-trace --stats: gemm_bench one <prec> <M> <N> <K> [kind: 0 f32+res, 1 gelu->planes]
+        const int prec = atoi(argv[2]), kind = argc > 6 ? atoi(argv[6]) : 0;
+        Case c = {"one", atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), kind, kind == 0, 0, kind == 1, kind == 0, 0, 0, 0, 1.f};
+        g_compare_nosplit = true;
+        double a = 0, b = 0;
+        for (int rep = 0; rep < 5; ++rep) run_case(prec, c, true, &a, &b);
+        printf("ONE prec=%d M=%d N=%d K=%d: with workspace %.1f us | without %.1f us\n", prec, c.M, c.N, c.K, a, b);
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "small")) {
         // products of short batches (rows = frames of 1 x 3 s, 1 x 10 s, 4 x 10 s, 1 x 60 s): split-K against no split
         g_compare_nosplit = true;
