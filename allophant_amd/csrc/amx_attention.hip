@@ -13,8 +13,13 @@
 //     registers feed O^T = V^T.P directly as the B operand (accumulator-as-operand order, cdna_hip_programming.md
 //     section 3); the matching V^T fragments (4 consecutive keys of one d per 64-bit half) come from the row-major V
 //     tile through the transposing LDS read ds_read_b64_tr_b16.
-//   * online softmax with a deferred maximum: the running maximum (and the O / l rescale) is only updated when some
-//     query's tile maximum exceeds it by more than 2^8; probabilities then stay <= 256, exact in the hi/lo planes.
+//   * online softmax with a deferred maximum: the score accumulators start at -m_run (no subtraction pass), the first
+//     tile sets m_run to its maximum, and afterwards m_run (with the O / l rescale) only moves when some query's tile
+//     maximum exceeds it by more than 2^8; probabilities then stay <= 256, exact in the hi/lo planes.
+//   * softmax on v_max3 trees, packed adds and packed 16-bit converts (v_cvt_pk_*), the hi/lo split of P two values
+//     at a time.  (Measured: explicit double-buffering of the LDS fragment reads, with the tile cut into two 32-key
+//     halves to stay inside the 128-VGPR budget of 4 waves per SIMD, was slower -- 4 waves per SIMD already hide the
+//     LDS latency.)
 // Masked keys (t' >= frame_len[n]) get -inf before the softmax; key tiles past the utterance end are skipped (their
 // probabilities are exactly 0 in the reference too: finfo.min bias underflows exp to 0).
 #include "amx_common.h"
@@ -29,8 +34,11 @@ constexpr int KT = 64;             // keys per tile
 constexpr int TILE = KT * 128;     // bytes of one K or V tile of one plane
 constexpr float DEFER_THR = 8.0f;  // log2 units
 
+#ifndef AMX_ATTN_OCC
+#define AMX_ATTN_OCC ((WAVES * 64) / 128)
+#endif
 template <typename T, int NT, int WAVES>
-__global__ __launch_bounds__(WAVES * 64, (WAVES * 64) / 128) void attn_kernel(const AttnParams p) {
+__global__ __launch_bounds__(WAVES * 64, AMX_ATTN_OCC) void attn_kernel(const AttnParams p) {
     typedef typename Vec8<T>::type V8;
     typedef typename Vec4<T>::type V4;
     typedef short s16x4 __attribute__((__vector_size__(8)));
@@ -89,9 +97,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * 64) / 128) void attn_kernel(co
 
     // ---- LDS read addresses ----
     // K fragment (c, ks): row 32c + lq, chunk (2ks + hh) ^ ((lq >> 1) & 7)
-    int kaddr[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) kaddr[ks] = lq * 128 + (((2 * ks + hh) ^ ((lq >> 1) & 7)) << 4);
+    // (2ks + hh) ^ s == (hh ^ s) ^ 2ks: one base register, the other three by a constant XOR at the use
+    const int kaddr0 = lq * 128 + ((hh ^ ((lq >> 1) & 7)) << 4);
     // V^T fragment half (c, s, g, dt): 16-lane group = 16 d columns x 4 keys; lane 4q + pp of the group addresses key row
     // 32c + 16s + 8g + 4hh + q, columns 32dt + 16*((lane >> 4) & 1) + 4pp .. +3   (chunk bit 2 swizzled by (q >> 1) & 1)
     int vaddr[2];
@@ -105,7 +112,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * 64) / 128) void attn_kernel(co
     f32x16 O[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { O[0][r] = 0.f; O[1][r] = 0.f; }
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = 0.f, l_run = 0.f;  // scores are kept relative to m_run; the first tile sets it
 
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -118,15 +125,16 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * 64) / 128) void attn_kernel(co
 
         // ---- S^T = K . Q^T : X[c][r] = score(key = kb + 32c + (r&3) + 8(r>>2) + 4hh, query), log2 units ----
         f32x16 X[2];
+        const float neg_m = -m_run;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) X[c][r] = 0.f;
+            for (int r = 0; r < 16; ++r) X[c][r] = neg_m;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const V8 kf = *(const V8*)(sb + c * 4096 + kaddr[ks]);
+                const V8 kf = *(const V8*)(sb + c * 4096 + (kaddr0 ^ (ks << 5)));
                 if (NT > 1) {
-                    const V8 kl = *(const V8*)(sb + 2 * TILE + c * 4096 + kaddr[ks]);
+                    const V8 kl = *(const V8*)(sb + 2 * TILE + c * 4096 + (kaddr0 ^ (ks << 5)));
                     X[c] = mfma32(kl, qf[0][ks], X[c]);
                     X[c] = mfma32(kf, qf[NT - 1][ks], X[c]);
                 }
@@ -135,49 +143,68 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * 64) / 128) void attn_kernel(co
         }
         const int kb = kt * KT;
         if (kb + KT > klen) {  // only the last tile holds masked keys (wave-uniform branch)
+            const int rem = klen - kb - 4 * hh;  // keys of this lane's rows left in the utterance
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = kb + 32 * c + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    X[c][r] = key < klen ? X[c][r] : -INFINITY;
-                }
+                for (int r = 0; r < 16; ++r) X[c][r] = 32 * c + (r & 3) + 8 * (r >> 2) < rem ? X[c][r] : -INFINITY;
         }
-        float mx = fmaxf(X[0][0], X[1][0]);
+        // scores are relative to the running maximum (the accumulators start at -m_run): tile maximum by v_max3 trees
+        float mx;
+        {
+            float t0 = fmaxf(fmaxf(X[0][0], X[0][1]), X[0][2]), t1 = fmaxf(fmaxf(X[1][0], X[1][1]), X[1][2]);
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(X[0][r], X[1][r]));
+            for (int r = 3; r + 1 < 16; r += 2) {
+                t0 = fmaxf(fmaxf(t0, X[0][r]), X[0][r + 1]);
+                t1 = fmaxf(fmaxf(t1, X[1][r]), X[1][r + 1]);
+            }
+            mx = fmaxf(fmaxf(t0, t1), fmaxf(X[0][15], X[1][15]));
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        if (!__all(mx <= m_run + DEFER_THR)) {  // wave-uniform; both lane halves of a query see the same mx, m_run
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            m_run = m_new;
+        // wave-uniform; both lane halves of a query see the same mx.  The first tile always takes its own maximum (m_run
+        // starts at 0, not at the scores' level); afterwards the maximum only moves when a tile exceeds it by 2^THR.
+        if (kt == 0 || !__all(mx <= DEFER_THR)) {
+            const float d = kt == 0 ? mx : fmaxf(mx, 0.f);
+            const float alpha = __builtin_amdgcn_exp2f(-d);
+            m_run += d;
             l_run *= alpha;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { O[0][r] *= alpha; O[1][r] *= alpha; }
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) X[c][r] -= d;
         }
-        float psum = 0.f;
+        f32x2 ps = {0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f(X[c][r] - m_run);
-                X[c][r] = e;
-                psum += e;
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 e = {__builtin_amdgcn_exp2f(X[c][r]), __builtin_amdgcn_exp2f(X[c][r + 1])};
+                X[c][r] = e[0];
+                X[c][r + 1] = e[1];
+                ps += e;  // v_pk_add_f32
             }
-        l_run += psum;
+        l_run += ps[0] + ps[1];
 
         // ---- O^T += V^T . P : P's accumulator registers are the B operand ----
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                V8 ph, pl_;
+                // hi/lo planes of 8 probabilities, two at a time on the packed converts (exp2 results are plain register
+                // values, so the single-value pinning of split16 is not needed here)
+                typedef typename Vec2<T>::type V2;
+                union { V2 h[4]; V8 v; } ph, pl_;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    T hi, lo = (T)0.f;
-                    split16<T, NT>(X[c][8 * s2 + j], hi, lo);
-                    ph[j] = hi;
-                    if (NT > 1) pl_[j] = lo;
+                for (int j = 0; j < 4; ++j) {
+                    const f32x2 x = {X[c][8 * s2 + 2 * j], X[c][8 * s2 + 2 * j + 1]};
+                    const V2 hi = __builtin_convertvector(x, V2);
+                    ph.h[j] = hi;
+                    if (NT > 1) {
+                        const f32x2 back = {(float)hi[0], (float)hi[1]};
+                        pl_.h[j] = __builtin_convertvector(x - back, V2);
+                    }
                 }
                 const int koff = c * 4096 + s2 * 2048;  // key rows 32c + 16s2 (+ 8g)
 #pragma unroll
@@ -188,10 +215,10 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES * 64) / 128) void attn_kernel(co
                     if (NT > 1) {
                         vl.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(sb + 2 * TILE + koff + vaddr[dt]));
                         vl.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(sb + 2 * TILE + koff + 1024 + vaddr[dt]));
-                        O[dt] = mfma32(vl.v, ph, O[dt]);
-                        O[dt] = mfma32(vf.v, pl_, O[dt]);
+                        O[dt] = mfma32(vl.v, ph.v, O[dt]);
+                        O[dt] = mfma32(vf.v, pl_.v, O[dt]);
                     }
-                    O[dt] = mfma32(vf.v, ph, O[dt]);
+                    O[dt] = mfma32(vf.v, ph.v, O[dt]);
                 }
             }
         // tile kt+1 has landed (this wave's pieces) and everyone is done reading tile kt

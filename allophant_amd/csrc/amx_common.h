@@ -11,6 +11,9 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
@@ -23,6 +26,9 @@ inline int prec_planes(int p) { return p >= 2 ? 2 : 1; }
 template <typename T> struct Vec8;
 template <> struct Vec8<f16> { typedef f16x8 type; };
 template <> struct Vec8<bf16> { typedef bf16x8 type; };
+template <typename T> struct Vec2;
+template <> struct Vec2<f16> { typedef f16x2 type; };
+template <> struct Vec2<bf16> { typedef bf16x2 type; };
 template <typename T> struct Vec4;
 template <> struct Vec4<f16> { typedef f16x4 type; };
 template <> struct Vec4<bf16> { typedef bf16x4 type; };
