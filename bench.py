@@ -69,17 +69,29 @@ def gemm_flops(spec, n, length, planes):
     products.append((M, spec["embedding_size"], D, 1))
     pp = tile = 0
     pp_launches = 0
-    for m, nn, k, cnt in products:
+    pp_bytes = 0  # algorithmic HBM bytes of the ping-pong launches: operands once (16-bit planes), outputs once
+    b16 = 2 * planes
+    for idx, (m, nn, k, cnt) in enumerate(products):
         fl = 2 * m * nn * k * cnt
         if nn >= 256 and nn % 4 == 0 and m >= 1024 and k % (128 // planes) == 0:
             pp += fl
             pp_launches += cnt
+            a_bytes = m * k * b16
+            if nn == C and k > C:  # conv layer: overlapping windows over n * T_in channels-last rows, read once
+                a_bytes = n * ts[last_conv] * C * b16
+            if (nn, k) in ((D, D), (D, F)) and cnt > 1:  # out-proj / FFN2: fp32 residual in, fp32 out
+                out_bytes, extra_in = m * nn * 4, m * nn * 4
+            elif (nn, k) == (D, C) or nn == C:  # feature projection / conv: fp32 out
+                out_bytes, extra_in = m * nn * 4, 0
+            else:  # QKV, FFN1, phoneme head: 16-bit planes out
+                out_bytes, extra_in = m * nn * b16, 0
+            pp_bytes += cnt * (a_bytes + nn * k * b16 + extra_in + out_bytes)
         else:
             tile += fl
     tile += 2 * M * D * (D // spec["pos_groups"]) * spec["pos_kernel"]  # grouped positional conv
     attention = spec["layers"] * 4 * M * T * D
     total = pp + ln + tile + attention + 2 * n * ts[1] * C * spec["conv_kernel"][0]
-    return {"gemm_pp": pp, "gemm_pp_launches": pp_launches, "gemm_ln": ln, "gemm_ln_launches": ln_launches, "gemm_tile": tile,
+    return {"gemm_pp": pp, "gemm_pp_launches": pp_launches, "gemm_pp_bytes": pp_bytes, "gemm_ln": ln, "gemm_ln_launches": ln_launches, "gemm_tile": tile,
             "attention": attention, "total": total, "frames_per_utt": T}
 
 
@@ -209,6 +221,7 @@ def main():
             "frac": achieved / MFMA_PEAK_TFLOPS if achieved else None,
             "traffic": load_traffic(precision),
             "flops_per_launch": fl["gemm_pp"] / fl["gemm_pp_launches"],
+            "algorithmic_bytes_per_launch": fl["gemm_pp_bytes"] / fl["gemm_pp_launches"],
             "avg_launch_ms": gemm_ms / gemm_launches if gemm_launches else None,
             "launches_per_step": gemm_launches // max(1, steps),
             "mfma_issue_factor": 3 if planes == 2 else 1,
