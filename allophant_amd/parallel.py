@@ -95,11 +95,29 @@ def gather_predictions(local: Optional[Predictions], names_and_classes: List[Tup
     return Predictions(outputs, all_lengths.cpu())
 
 
-def gather_flat_predictions(local: Predictions, device: torch.device, dst: int = 0, group=None) -> Optional[Predictions]:
+class PendingGather:
+    """Handle of an asynchronous ``gather_flat_predictions``: the collectives are in flight on the backend's own stream
+    (RCCL: beside the compute stream, so the gather of batch k overlaps the forward pass of batch k + 1); ``wait()`` makes
+    the current stream wait for them and returns the assembled ``Predictions`` on the destination rank, ``None`` elsewhere.
+    The handle keeps the send buffers alive until then."""
+
+    def __init__(self, works, keep, assemble):
+        self._works, self._keep, self._assemble = works, keep, assemble
+
+    def wait(self) -> Optional[Predictions]:
+        for work in self._works:
+            work.wait()
+        result = self._assemble() if self._assemble is not None else None
+        self._works, self._keep, self._assemble = [], None, None
+        return result
+
+
+def gather_flat_predictions(local: Predictions, device: torch.device, dst: int = 0, group=None, async_op: bool = False):
     """Fast path for equal-shaped shards (every rank ran the same ``(N, L)`` geometry, e.g. the weak-scaling benchmark):
     the outputs of ``Estimator.predict`` are views of one flat fp32 block, so a single ``gather`` of that block (plus one
     of the frame lengths) moves everything; rank ``dst`` re-assembles ``[T, world * N, C]`` per output with one strided
-    copy each.  Returns the assembled ``Predictions`` on ``dst`` and ``None`` elsewhere."""
+    copy each.  Returns the assembled ``Predictions`` on ``dst`` and ``None`` elsewhere -- or, with ``async_op=True``, a
+    ``PendingGather`` whose ``wait()`` returns that."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     flat = local._flat
@@ -107,27 +125,30 @@ def gather_flat_predictions(local: Predictions, device: torch.device, dst: int =
         raise ValueError("gather_flat_predictions needs Predictions produced by Estimator.predict (one flat output block)")
     n = len(local.lengths)
     stacked = torch.empty(world, flat.numel(), dtype=flat.dtype, device=device) if rank == dst else None
-    dist.gather(flat, [stacked[r] for r in range(world)] if rank == dst else None, dst=dst, group=group)
+    w1 = dist.gather(flat, [stacked[r] for r in range(world)] if rank == dst else None, dst=dst, group=group, async_op=True)
     lens = local.lengths.to(device)
     all_lens = torch.empty(world, n, dtype=lens.dtype, device=device) if rank == dst else None
-    dist.gather(lens, [all_lens[r] for r in range(world)] if rank == dst else None, dst=dst, group=group)
-    if rank != dst:
-        return None
-    outputs: Dict[str, Tensor] = {}
-    done: Dict[int, str] = {}
-    base = flat.data_ptr()
-    for name, out in local.outputs.items():
-        key = out.data_ptr()
-        if key in done:  # aliases ("phone" / "phoneme") share storage upstream too (acoustic_model.py:161-167)
-            outputs[name] = outputs[done[key]]
-            continue
-        t, _, c = out.shape
-        first = (key - base) // flat.element_size()
-        block = stacked[:, first: first + t * n * c].view(world, t, n, c)
-        outputs[name] = block.permute(1, 0, 2, 3).reshape(t, world * n, c)
-        done[key] = name
-    # frame lengths stay on `device`: a host copy here would serialise the caller with the stream every step
-    return Predictions(outputs, all_lens.reshape(-1))
+    w2 = dist.gather(lens, [all_lens[r] for r in range(world)] if rank == dst else None, dst=dst, group=group, async_op=True)
+
+    def assemble() -> Predictions:
+        outputs: Dict[str, Tensor] = {}
+        done: Dict[int, str] = {}
+        base = flat.data_ptr()
+        for name, out in local.outputs.items():
+            key = out.data_ptr()
+            if key in done:  # aliases ("phone" / "phoneme") share storage upstream too (acoustic_model.py:161-167)
+                outputs[name] = outputs[done[key]]
+                continue
+            t, _, c = out.shape
+            first = (key - base) // flat.element_size()
+            block = stacked[:, first: first + t * n * c].view(world, t, n, c)
+            outputs[name] = block.permute(1, 0, 2, 3).reshape(t, world * n, c)
+            done[key] = name
+        # frame lengths stay on `device`: a host copy here would serialise the caller with the stream every step
+        return Predictions(outputs, all_lens.reshape(-1))
+
+    pending = PendingGather([w1, w2], (flat, lens, stacked, all_lens), assemble if rank == dst else None)
+    return pending if async_op else pending.wait()
 
 
 def unique_outputs(predictions: Predictions) -> Tuple[List[Tuple[str, int]], Dict[str, str]]:

@@ -169,24 +169,37 @@ def main():
         est = Estimator(spec, state, device, precision)
         batch = Batch(audio.to(device), lengths, torch.zeros(n, dtype=torch.long))
 
+        pending = [None]
+
         def step(timing=False):
             pred = est.predict(batch, tfi, True, _timing=timing)
             if use_dist:
                 # RCCL gather of the per-frame log-probabilities (one flat fp32 block per rank) + frame lengths to rank 0,
-                # which re-assembles `Predictions` of the global batch: [T, n * world, C] per output
-                gathered = parallel.gather_flat_predictions(pred, device, dst=0)
-                if rank == 0:
-                    return gathered.outputs, gathered.lengths
+                # which re-assembles `Predictions` of the global batch: [T, n * world, C] per output.  The gather of step k
+                # is asynchronous and overlaps the forward pass of step k + 1; it is completed (and assembled on rank 0)
+                # before step k + 2 is enqueued, and `drain()` completes the last one inside the timed region.
+                previous, pending[0] = pending[0], parallel.gather_flat_predictions(pred, device, dst=0, async_op=True)
+                if previous is not None:
+                    gathered = previous.wait()
+                    if rank == 0:
+                        return gathered.outputs, gathered.lengths
             return pred.outputs, pred.lengths
+
+        def drain():
+            if pending[0] is not None:
+                pending[0].wait()
+                pending[0] = None
 
         for _ in range(warmup):
             step()
+        drain()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
+        drain()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -200,6 +213,7 @@ def main():
         est.timing_fetch()
         for _ in range(steps):
             step(timing=True)
+        drain()
         torch.cuda.synchronize()
         timing = est.timing_fetch()
         est.close()

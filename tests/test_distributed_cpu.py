@@ -103,7 +103,12 @@ def _flat_worker(rank, world, port, result_path):
         outputs[name] = view
         off += t * n * c
     local = Predictions(outputs, torch.tensor([5, 4, 2]) + rank, _flat=flat)
-    gathered = gather_flat_predictions(local, torch.device("cpu"), dst=0)
+    if rank == 0:
+        # the asynchronous form (bench.py overlaps the gather of step k with the forward pass of step k + 1)
+        handle = gather_flat_predictions(local, torch.device("cpu"), dst=0, async_op=True)
+        gathered = handle.wait()
+    else:
+        gathered = gather_flat_predictions(local, torch.device("cpu"), dst=0)
     if rank == 0:
         torch.save({"outputs": gathered.outputs, "lengths": gathered.lengths}, result_path)
     else:
