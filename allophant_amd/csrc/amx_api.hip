@@ -350,10 +350,10 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
     if (hipMalloc(&staging, (size_t)max_numel * 4 + 16) != hipSuccess) { h->err = "staging allocation failed"; return bail(AMX_ENOMEM); }
     struct StagingGuard {
         float* p;
-        ~StagingGuard() { hipFree(p); }
+        ~StagingGuard() { (void)hipFree(p); }
     } guard{staging};
 
-    const int C = cfg->conv_dim, D = cfg->hidden, F = cfg->ffn, NTp = h->NT;
+    const int C = cfg->conv_dim, D = cfg->hidden, F = cfg->ffn;
     const float eps = cfg->eps;
     (void)eps;
     int rc;
@@ -568,18 +568,19 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
 
 extern "C" int amx_destroy(amx_handle h) {
     if (!h) return AMX_OK;
-    hipSetDevice(h->device);
-    hipDeviceSynchronize();
-    for (void* p : h->allocs) hipFree(p);
+    // teardown is best effort: a failing release cannot be reported more usefully than by carrying on
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    for (void* p : h->allocs) (void)hipFree(p);
     for (auto& kv : h->ws)
-        if (kv.second.p) hipFree(kv.second.p);
+        if (kv.second.p) (void)hipFree(kv.second.p);
     for (int i = 0; i < amx_handle_s::PIN_SLOTS; ++i) {
-        if (h->h_lengths_pinned[i]) hipHostFree(h->h_lengths_pinned[i]);
-        if (h->h_frames_pinned[i]) hipHostFree(h->h_frames_pinned[i]);
-        if (h->pin_event[i]) hipEventDestroy(h->pin_event[i]);
+        if (h->h_lengths_pinned[i]) (void)hipHostFree(h->h_lengths_pinned[i]);
+        if (h->h_frames_pinned[i]) (void)hipHostFree(h->h_frames_pinned[i]);
+        if (h->pin_event[i]) (void)hipEventDestroy(h->pin_event[i]);
     }
-    for (auto& sp : h->spans) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
-    for (auto e : h->event_pool) hipEventDestroy(e);
+    for (auto& sp : h->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+    for (auto e : h->event_pool) (void)hipEventDestroy(e);
     delete h;
     return AMX_OK;
 }
@@ -752,7 +753,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     if (h->pinned_cap < N) {
         HIPCHK(h, hipStreamSynchronize(s));
         for (int i = 0; i < amx_handle_s::PIN_SLOTS; ++i) {
-            if (h->h_lengths_pinned[i]) { hipHostFree(h->h_lengths_pinned[i]); hipHostFree(h->h_frames_pinned[i]); }
+            if (h->h_lengths_pinned[i]) { (void)hipHostFree(h->h_lengths_pinned[i]); (void)hipHostFree(h->h_frames_pinned[i]); }
             HIPCHK(h, hipHostMalloc((void**)&h->h_lengths_pinned[i], (size_t)N * 8));
             HIPCHK(h, hipHostMalloc((void**)&h->h_frames_pinned[i], (size_t)N * 4));
             if (!h->pin_event[i]) HIPCHK(h, hipEventCreateWithFlags(&h->pin_event[i], hipEventDisableTiming));

@@ -369,3 +369,75 @@ def test_full_size_properties(amd):
                 assert (h.timesteps[1:] > h.timesteps[:-1]).all()
             assert len(h.timesteps) == 0 or (1 <= int(h.timesteps[0]) and int(h.timesteps[-1]) <= int(pred.lengths[n]))
     est.close()
+
+
+def _random_spec(rng):
+    """A random classifier graph over a tiny encoder: 2-5 attribute classes of random width, some depending on earlier
+    ones and on intermediate hidden states (OUTPUT_i), some behind a time layer, with or without blank columns in the
+    dependency softmaxes, phoneme head plain or composed, with or without the allophone pass-through."""
+    layers = int(rng.integers(1, 4))
+    enc = S.tiny_encoder(layers)
+    names = ["syllabic", "long", "nasal", "round", "tap"][: int(rng.integers(2, 6))]
+    composed = bool(rng.integers(0, 2))
+    embedding = int(rng.choice([8, 16, 40])) if composed else 0
+    if composed:
+        spec = S.multitask_spec(enc, names, embedding_size=embedding, train_phonemes=int(rng.integers(3, 12)),
+                                n_features=int(rng.integers(2, 7)), allophone_layer=bool(rng.integers(0, 2)))
+    else:
+        spec = S.multitask_spec(enc, names, embedding_size=8, train_phonemes=int(rng.integers(3, 40)), n_features=2,
+                                allophone_layer=bool(rng.integers(0, 2)))
+        spec["embedding_size"] = None
+        spec["composition_categories"] = None
+    spec["dependency_blanks"] = bool(rng.integers(0, 2))
+    if spec["allophone_layer"]:
+        spec["shared_phones"] = int(rng.integers(5, 30))
+    by_name = {c["name"]: c for c in spec["classes"]}
+    for i, name in enumerate(names):
+        c = by_name[name]
+        c["size"] = int(rng.integers(1, 7))
+        deps = []
+        if i > 0 and rng.integers(0, 2):
+            deps += [str(d) for d in rng.choice(names[:i], size=int(rng.integers(1, i + 1)), replace=False)]
+        deps.append(S.OUTPUT if rng.integers(0, 3) else f"{S.OUTPUT}_{int(rng.integers(0, layers + 1))}")
+        rng.shuffle(deps)
+        c["dependencies"] = deps
+        if rng.integers(0, 4) == 0:
+            width = c["size"] + 1
+            heads = int(rng.choice([h for h in (1, 2, 3) if width % h == 0]))
+            c["time_layer"] = {"num_heads": heads, "positional_embeddings": bool(width % 2 == 0 and rng.integers(0, 2))}
+    phoneme = by_name[S.PHONEME]
+    extra = [str(d) for d in rng.choice(names, size=int(rng.integers(0, len(names) + 1)), replace=False)]
+    phoneme["dependencies"] = [S.OUTPUT] + extra
+    S.validate(spec)
+    return spec
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_models_and_geometries_against_oracle(amd, seed):
+    """Randomised classifier graphs, inventories and ragged batch geometries (1-6 utterances of 400-20 000 samples,
+    including single-frame utterances) against the CPU oracle, in the parity mode."""
+    from oracle import allophant_oracle as O
+
+    rng = np.random.default_rng(1000 + seed)
+    spec = _random_spec(rng)
+    state = synthetic.make_state_dict(spec, seed=seed)
+    composed = bool(spec.get("embedding_size"))
+    est = amd.Estimator(spec, state, "cuda:0", "f16x3")
+    for geometry in range(2):
+        n = int(rng.integers(1, 7))
+        length = int(rng.integers(400, 20001))
+        audio, lengths = synthetic.make_audio(n, length, seed=seed * 10 + geometry, ragged=True)
+        lengths = torch.clamp(lengths, min=400)
+        if n > 1 and rng.integers(0, 2):
+            lengths[-1] = 400 + int(rng.integers(0, 320))  # one or two output frames
+        for i in range(n):
+            audio[i, int(lengths[i]):] = 0
+        tfi = synthetic.make_inventory(spec, int(rng.integers(1, 15)), seed=seed + geometry) if composed else None
+        offsets = synthetic.category_offsets(spec) if composed else None
+        pred = est.predict(amd.Batch(audio.cuda(), lengths, torch.zeros(n, dtype=torch.long)), tfi)
+        ref, ref_len = O.predict(audio, lengths, state, spec, tfi, offsets)
+        assert list(pred.outputs) == list(ref) and torch.equal(pred.lengths.cpu(), ref_len)
+        for k in ref:
+            assert pred.outputs[k].shape == ref[k].shape, k
+            assert max_abs_valid_tm(pred.outputs[k].cpu(), ref[k], ref_len) < GATE, (seed, geometry, k)
+    est.close()
