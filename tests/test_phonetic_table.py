@@ -98,3 +98,26 @@ def test_checkpoint_layout_is_rebuilt_from_the_embedded_table(golden, allophone_
         ckpt["phonetic_indexer_state"]["language_allophones"]["shared_phones"] = ["a"]
     with pytest.raises(ValueError, match="attribute embeddings"):
         checkpoint.spec_from_checkpoint(ckpt)
+
+
+def test_hypothesis_symbols_follow_the_reference_prediction_loop():
+    """tokens - 1 -> inventory symbols on the IPA outputs, category strings on attribute outputs (run.py:776-806)."""
+    from collections import namedtuple
+
+    from allophant_amd.phonetic import AttributeTable, hypothesis_symbols
+
+    Hyp = namedtuple("Hyp", "tokens timesteps score")
+    with open(GOLDEN, encoding="utf-8") as f:
+        table = AttributeTable(json.load(f)["table"])
+    inventory = table.phonemes[:4]
+    feature = table.composition_features[0]
+    categories = table.feature_categories(feature)
+    decoded = {
+        "phoneme": [[Hyp(torch.tensor([2, 1, 3]), torch.tensor([1, 4, 6]), -1.0)], [Hyp(torch.tensor([], dtype=torch.int64), torch.tensor([]), 0.0)]],
+        feature: [[Hyp(torch.tensor([1, len(categories)]), torch.tensor([1, 2]), -2.0)], [Hyp(torch.tensor([1]), torch.tensor([3]), -0.5)]],
+    }
+    symbols = hypothesis_symbols(decoded, inventory, table)
+    assert symbols["phoneme"] == [[[inventory[1], inventory[0], inventory[2]]], [[]]]
+    assert symbols[feature] == [[[categories[0], categories[-1]]], [[categories[0]]]]
+    assert table.feature_values(feature, torch.tensor([0])) == [categories[0]]
+    assert hypothesis_symbols({feature: decoded[feature]}, inventory)[feature][0][0] == ["0", str(len(categories) - 1)]
