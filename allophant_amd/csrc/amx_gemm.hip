@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void splitk_fixup_kernel(const GemmParams p, c
 // Requires K % (128 / planes) == 0, N % 4 == 0, 16-byte aligned operand rows.
 // ---------------------------------------------------------------------------------------------------------------
 namespace pp {
-constexpr int BM = 256, BN = 256, KS = 32;
+constexpr int BN = 256, KS = 32;  // tile rows: 32 x MI (template parameter of the kernel)
 constexpr int SLOT = 32768, W_OFF = 16384, NSLOT = 4;
 constexpr int EPI_BASE = 2 * SLOT;        // epilogue patches: slots 2-3
 constexpr int EPI_WAVE = 32 * 64 * 4;     // bytes of epilogue patch per wave: 32 rows x 64 fp32
@@ -352,7 +352,8 @@ __device__ __forceinline__ void mfma16_acc(f32x4& c, bf16x8 a, bf16x8 b) {
 }
 
 // stage accumulator fragments 2q, 2q+1 (32 rows x 64 columns) of the wave block into its fp32 LDS patch
-__device__ __forceinline__ void pp_stage_round(float* es, f32x4 (&acc)[4][8], int q, int lane) {
+template <int MI>
+__device__ __forceinline__ void pp_stage_round(float* es, f32x4 (&acc)[4][MI], int q, int lane) {
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -363,8 +364,8 @@ __device__ __forceinline__ void pp_stage_round(float* es, f32x4 (&acc)[4][8], in
 // ---- branch-free epilogues for interior wave blocks (all 128 x 64 outputs in range, no row mask) ----
 // fp32 output (+ bias, + residual): a lane owns 4 consecutive columns; 16 lanes cover a 256-byte row segment.
 // All loads of a 32-row round are issued before the first use, all stores after: no wait inside the round.
-template <bool RES>
-__device__ __forceinline__ void pp_epilogue_f32(const GemmParams& p, f32x4 (&acc)[4][8], float* es, int lane, int mw, int nw,
+template <bool RES, int MI>
+__device__ __forceinline__ void pp_epilogue_f32(const GemmParams& p, f32x4 (&acc)[4][MI], float* es, int lane, int mw, int nw,
                                                 float* out_f32) {
     const int ch = lane & 15, rq = (lane >> 4) * 8;  // rows rq + i: every 16-lane group reads rows of equal row & 7
     const int n = nw + ch * 4;
@@ -374,7 +375,7 @@ __device__ __forceinline__ void pp_epilogue_f32(const GemmParams& p, f32x4 (&acc
     float* optr = out_f32 + (int64_t)(mw + rq) * p.ldo + n;
     const float* rptr = RES ? p.residual + (int64_t)(mw + rq) * p.ldr + n : nullptr;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < MI / 2; ++q) {
         float4 r[8];
         if (RES) {
 #pragma unroll
@@ -396,8 +397,8 @@ __device__ __forceinline__ void pp_epilogue_f32(const GemmParams& p, f32x4 (&acc
 
 // 16-bit plane output (+ bias, optional GELU), or the Q / K / V scatter of the fused QKV projection (QK): a lane owns 8
 // consecutive columns (one 16-byte store per plane); 8 lanes cover the 128-byte row segment of the wave block.
-template <typename T, int NT, bool ACT, bool QK>
-__device__ __forceinline__ void pp_epilogue_p16(const GemmParams& p, f32x4 (&acc)[4][8], float* es, int lane, int mw, int nw) {
+template <typename T, int NT, bool ACT, bool QK, int MI>
+__device__ __forceinline__ void pp_epilogue_p16(const GemmParams& p, f32x4 (&acc)[4][MI], float* es, int lane, int mw, int nw) {
     typedef typename Vec8<T>::type V8;
     const int c8 = lane & 7, rs = lane >> 3;  // rows rs + 8i
     const int n = nw + c8 * 8;
@@ -423,7 +424,7 @@ __device__ __forceinline__ void pp_epilogue_p16(const GemmParams& p, f32x4 (&acc
         plane = p.out_plane;
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < MI / 2; ++q) {
         pp_stage_round(es, acc, q, lane);
         f32x4 c[4][2];
 #pragma unroll
@@ -462,8 +463,8 @@ __device__ __forceinline__ void pp_epilogue_p16(const GemmParams& p, f32x4 (&acc
 }
 
 // edge blocks (M / N tails), row masks, combined fp32 + plane outputs: every feature, runtime flags
-template <typename T, int NT>
-__device__ __forceinline__ void pp_epilogue_generic(const GemmParams& p, f32x4 (&acc)[4][8], float* es, int lane, int mw, int nw,
+template <typename T, int NT, int MI>
+__device__ __forceinline__ void pp_epilogue_generic(const GemmParams& p, f32x4 (&acc)[4][MI], float* es, int lane, int mw, int nw,
                                                     float* out_f32) {
     typedef typename Vec4<T>::type V4;
     const int D = p.H * p.dh;
@@ -485,7 +486,7 @@ __device__ __forceinline__ void pp_epilogue_generic(const GemmParams& p, f32x4 (
     const bool need_bt = p.row_len || p.mode == 1;
     const int rt = p.mode == 1 ? p.T : p.rows_T;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < MI / 2; ++q) {
         pp_stage_round(es, acc, q, lane);
         // LDS operations of one wave complete in order: the reads below see the writes above
         int b = 0, t = 0;
@@ -545,8 +546,13 @@ __device__ __forceinline__ void pp_epilogue_generic(const GemmParams& p, f32x4 (
     }
 }
 
-template <typename T, int NT>
+// MI = accumulator fragments per wave along M: 8 -> the 256 x 256 tile described above; 4 -> a 128 x 256 tile (wave tile
+// 64 x 64, one A piece per wave and sub-step, 16 MFMAs per segment) for products whose 256-row tiles cannot fill the chip.
+template <typename T, int NT, int MI>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
+    constexpr int BMK = MI * 32;   // tile rows
+    constexpr int HALF = MI * 16;  // rows of a wave group
+    constexpr int APW = MI / 4;    // A pieces (16 rows x 64 B) per wave and sub-step
     typedef typename Vec8<T>::type V8;
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -555,7 +561,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wc = wave & 3;
-    const int ntn = (p.N + pp::BN - 1) / pp::BN, ntm = (p.M + pp::BM - 1) / pp::BM;
+    const int ntn = (p.N + pp::BN - 1) / pp::BN, ntm = (p.M + BMK - 1) / BMK;
     const int tiles = ntn * ntm;
     // split-K (p.splits > 1, set by launch_gemm for products with too few tiles to fill the chip): a work unit is
     // (tile, K chunk of p.K elements); chunk ks reads A / W columns [ks * p.K, (ks + 1) * p.K) and writes its raw fp32
@@ -564,12 +570,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 
     // ---- fragment read offsets (bytes inside a slot) ----
     const int rd_chunk = ((lane >> 4) ^ ((lane >> 2) & 2)) << 4;
-    const int a_rd = (grp * 128 + (lane & 15)) * 64 + rd_chunk;
+    const int a_rd = (grp * HALF + (lane & 15)) * 64 + rd_chunk;
     const int w_rd = pp::W_OFF + (wc * 64 + (lane & 15)) * 64 + rd_chunk;
     const uint32_t a_plane_b = (uint32_t)(p.a_plane * 2), w_plane_b = (uint32_t)(p.w_plane * 2);
 
-    // ---- per-tile DMA state: this wave fills pieces 2*wave, 2*wave+1 (16 rows x 64 B each) of the A part and of the
-    // W part of a slot; addresses are (wave-uniform tile base in an SGPR buffer descriptor) + (32-bit per-lane offset)
+    // ---- per-tile DMA state: this wave fills pieces APW*wave.. (16 rows x 64 B each) of the A part and 2*wave, 2*wave+1
+    // of the W part of a slot; addresses are (wave-uniform tile base in an SGPR buffer descriptor) + (32-bit per-lane offset)
     int m0 = 0, n0 = 0, ks = 0;
     __amdgpu_buffer_rsrc_t a_rsrc, w_rsrc;
     uint32_t a_off[2], w_off[2];
@@ -589,7 +595,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         const int first_m = group * GM;
         const int gsize = ntm - first_m < GM ? ntm - first_m : GM;
         const int in_group = j - group * per_group;
-        m0 = (first_m + in_group % gsize) * pp::BM;
+        m0 = (first_m + in_group % gsize) * BMK;
         n0 = (in_group / gsize) * pp::BN;
         const int m0c = m0 < p.M ? m0 : p.M - 1, n0c = n0 < p.N ? n0 : p.N - 1;
         const int64_t b0 = m0c / p.rows_per_batch;
@@ -598,31 +604,37 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.A + a_tile + k_first), 0, -1, 0x00020000);
         w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.W + (int64_t)n0c * p.ldw + k_first), 0, -1, 0x00020000);
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            const int row = (wave * 2 + jj) * 16 + ((tid & 63) >> 2);
+        for (int jj = 0; jj < APW; ++jj) {
+            const int row = (wave * APW + jj) * 16 + ((tid & 63) >> 2);
             const int lc = (tid & 3) ^ ((row >> 2) & 2);  // logical 16-byte chunk stored at physical chunk lane & 3
             int rr = m0 + row;
             rr = rr < p.M ? rr : p.M - 1;
             const int64_t b = rr / p.rows_per_batch;
             const int64_t t = rr - b * p.rows_per_batch;
             a_off[jj] = (uint32_t)((b * p.a_batch_stride + t * p.lda - a_tile + lc * 8) * 2);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int row = (wave * 2 + jj) * 16 + ((tid & 63) >> 2);
+            const int lc = (tid & 3) ^ ((row >> 2) & 2);
             int rn = n0 + row;
             rn = rn < p.N ? rn : p.N - 1;
             w_off[jj] = (uint32_t)(((int64_t)(rn - n0c) * p.ldw + lc * 8) * 2);
         }
     };
 
-    f32x4 acc[4][8];
-    V8 fa[NT][8], fw[NT][4];
+    f32x4 acc[4][MI];
+    V8 fa[NT][MI], fw[NT][4];
 
     // DMA of the A part and / or W part of (plane, k-offset) into a ring slot
     auto stage = [&](int slot, int plane, bool do_a, bool do_w, int koff) {
         unsigned char* dst = smem + slot * pp::SLOT + wave * 2048;
         if (do_a) {
             const uint32_t so = plane * a_plane_b + (uint32_t)koff * 2;
+            unsigned char* dst_a = smem + slot * pp::SLOT + wave * (APW * 1024);
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_ptr_t)(dst + j * 1024), 16, a_off[j], so, 0, 0);
+            for (int j = 0; j < APW; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_ptr_t)(dst_a + j * 1024), 16, a_off[j], so, 0, 0);
         }
         if (do_w) {
             const uint32_t so = plane * w_plane_b + (uint32_t)koff * 2;
@@ -644,11 +656,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 
     // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate)
     auto wait_dma = [](int keep) {
-        if (keep >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (keep >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else if (keep >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (keep >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        switch (keep) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        }
     };
 #ifdef AMX_PP_STAMP
     // developer diagnostic (tools/gemm_bench.hip, -DAMX_PP_STAMP): cycles per phase of the LOAD / MFMA segments, summed
@@ -675,7 +693,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         constexpr int C = decltype(code)::value;
         constexpr int RS = C & 3, RA = (C >> 2) & 1, RW = (C >> 3) & 1, DPL = (C >> 4) & 1, PROD = (C >> 5) & 3,
                       SS = (C >> 7) & 3, SPL = (C >> 9) & 1, CNT2 = (C >> 10) & 7;
-        constexpr int CNT3 = 2 * (RA + RW);
+        constexpr int CNT3 = APW * RA + 2 * RW;
         // DMA pieces that may stay in flight past this segment's wait: those of sub-steps u+2 and u+3
         const int keep = (stage_ok ? CNT3 : 0) + (next2_ok ? CNT2 : 0);
         // ---------------- LOAD segment ----------------
@@ -686,7 +704,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         const unsigned char* s = smem + RS * pp::SLOT;
         if (RA) {
 #pragma unroll
-            for (int mi = 0; mi < 8; ++mi) fa[DPL][mi] = *(const V8*)(s + a_rd + mi * 1024);
+            for (int mi = 0; mi < MI; ++mi) fa[DPL][mi] = *(const V8*)(s + a_rd + mi * 1024);
         }
         if (RW) {
 #pragma unroll
@@ -712,7 +730,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-            for (int mi = 0; mi < 8; ++mi) mfma16_acc(acc[ni][mi], fw[PW][ni], fa[PA][mi]);
+            for (int mi = 0; mi < MI; ++mi) mfma16_acc(acc[ni][mi], fw[PW][ni], fa[PA][mi]);
         __builtin_amdgcn_s_setprio(0);
 #ifdef AMX_PP_STAMP
         const unsigned long long t3 = stamp();
@@ -738,7 +756,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #ifdef AMX_PP_STAMP
         const unsigned long long st_l0 = stamp();
         st_prev = 0;
@@ -747,29 +765,29 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
             // segments = 32-deep K slices; slice u lives in slot u % 4
             const int nseg = p.K / pp::KS;
             stage(2, 0, true, true, 2 * pp::KS);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // slice 0 has landed
+            wait_dma(2 * (APW + 2));  // slice 0 has landed
             __builtin_amdgcn_s_barrier();
             if (grp == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind group 0
             for (int u = 0; u < nseg; u += 4) {
-                segment(PP_CODE(0, 1, 1, 0, 0, 3, 0, 4), u + 3 < nseg, (u + 3) * pp::KS, u + 2 < nseg);
-                segment(PP_CODE(1, 1, 1, 0, 0, 0, 0, 4), u + 4 < nseg, (u + 4) * pp::KS, u + 3 < nseg);
-                segment(PP_CODE(2, 1, 1, 0, 0, 1, 0, 4), u + 5 < nseg, (u + 5) * pp::KS, u + 4 < nseg);
-                segment(PP_CODE(3, 1, 1, 0, 0, 2, 0, 4), u + 6 < nseg, (u + 6) * pp::KS, u + 5 < nseg);
+                segment(PP_CODE(0, 1, 1, 0, 0, 3, 0, APW + 2), u + 3 < nseg, (u + 3) * pp::KS, u + 2 < nseg);
+                segment(PP_CODE(1, 1, 1, 0, 0, 0, 0, APW + 2), u + 4 < nseg, (u + 4) * pp::KS, u + 3 < nseg);
+                segment(PP_CODE(2, 1, 1, 0, 0, 1, 0, APW + 2), u + 5 < nseg, (u + 5) * pp::KS, u + 4 < nseg);
+                segment(PP_CODE(3, 1, 1, 0, 0, 2, 0, APW + 2), u + 6 < nseg, (u + 6) * pp::KS, u + 5 < nseg);
             }
         } else {
             // hi planes of slice k in slot 2*(k%2), lo planes in slot 2*(k%2)+1
             const int nk = p.K / pp::KS;
-            stage(1, 1, true, false, 0);                      // LA(0)
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // H(0) has landed
+            stage(1, 1, true, false, 0);  // LA(0)
+            wait_dma(2 + APW);            // H(0) has landed
             __builtin_amdgcn_s_barrier();
             if (grp == 1) __builtin_amdgcn_s_barrier();
             for (int k = 0; k < nk; k += 2) {  // nk is even
                 const bool ok2 = k + 2 < nk;
-                segment(PP_CODE(0, 1, 1, 0, 0, 2, 0, 2), true, (k + 1) * pp::KS, true);
-                segment(PP_CODE(1, 0, 1, 1, 1, 3, 1, 4), true, (k + 1) * pp::KS, true);
+                segment(PP_CODE(0, 1, 1, 0, 0, 2, 0, APW), true, (k + 1) * pp::KS, true);
+                segment(PP_CODE(1, 0, 1, 1, 1, 3, 1, APW + 2), true, (k + 1) * pp::KS, true);
                 segment(PP_CODE(1, 1, 0, 1, 2, 3, 1, 2), true, (k + 1) * pp::KS, true);
-                segment(PP_CODE(2, 1, 1, 0, 0, 0, 0, 2), ok2, (k + 2) * pp::KS, true);
-                segment(PP_CODE(3, 0, 1, 1, 1, 1, 1, 4), ok2, (k + 2) * pp::KS, ok2);
+                segment(PP_CODE(2, 1, 1, 0, 0, 0, 0, APW), ok2, (k + 2) * pp::KS, true);
+                segment(PP_CODE(3, 0, 1, 1, 1, 1, 1, APW + 2), ok2, (k + 2) * pp::KS, ok2);
                 segment(PP_CODE(3, 1, 0, 1, 2, 1, 1, 2), ok2, (k + 2) * pp::KS, ok2);
             }
         }
@@ -780,7 +798,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #endif
 
         // ---- next tile: set up its DMA state and start its first two sub-steps under this tile's epilogue ----
-        const int mw = m0 + grp * 128, nw = n0 + wc * 64;
+        const int mw = m0 + grp * HALF, nw = n0 + wc * 64;
         float* out_f32 = p.out_f32 ? p.out_f32 + (int64_t)ks * p.split_out : nullptr;
         const int next = it + gridDim.x;
         const bool has_next = next < total;
@@ -796,30 +814,30 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         if (nw < p.N && mw < p.M) {
             float* es = (float*)(smem + pp::EPI_BASE + wave * pp::EPI_WAVE);
             bool done = false;
-            if (mw + 128 <= p.M && nw + 64 <= p.N && !p.row_len && p.vec_ok) {
+            if (mw + HALF <= p.M && nw + 64 <= p.N && !p.row_len && p.vec_ok) {
                 // interior block: branch-free epilogues
                 if (p.mode == 1) {
                     if (p.T >= 8 && p.dh % 8 == 0 && p.qk_plane % 8 == 0 && !(((uintptr_t)p.q | (uintptr_t)p.k | (uintptr_t)p.v) & 15)) {
-                        pp_epilogue_p16<T, NT, false, true>(p, acc, es, lane, mw, nw);
+                        pp_epilogue_p16<T, NT, false, true, MI>(p, acc, es, lane, mw, nw);
                         done = true;
                     }
                 } else if (p.out_f32 && !p.out_p && p.act == 0) {
-                    if (p.residual) pp_epilogue_f32<true>(p, acc, es, lane, mw, nw, out_f32);
-                    else pp_epilogue_f32<false>(p, acc, es, lane, mw, nw, out_f32);
+                    if (p.residual) pp_epilogue_f32<true, MI>(p, acc, es, lane, mw, nw, out_f32);
+                    else pp_epilogue_f32<false, MI>(p, acc, es, lane, mw, nw, out_f32);
                     done = true;
                 } else if (p.out_p && !p.out_f32 && !p.residual && p.ldp % 8 == 0 && p.out_plane % 8 == 0 && !((uintptr_t)p.out_p & 15)) {
-                    if (p.act == 1) pp_epilogue_p16<T, NT, true, false>(p, acc, es, lane, mw, nw);
-                    else pp_epilogue_p16<T, NT, false, false>(p, acc, es, lane, mw, nw);
+                    if (p.act == 1) pp_epilogue_p16<T, NT, true, false, MI>(p, acc, es, lane, mw, nw);
+                    else pp_epilogue_p16<T, NT, false, false, MI>(p, acc, es, lane, mw, nw);
                     done = true;
                 }
             }
-            if (!done) pp_epilogue_generic<T, NT>(p, acc, es, lane, mw, nw, out_f32);
+            if (!done) pp_epilogue_generic<T, NT, MI>(p, acc, es, lane, mw, nw, out_f32);
         }
 #else
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(acc[i][j]));
+            for (int j = 0; j < MI; ++j) asm volatile("" ::"v"(acc[i][j]));
 #endif
         if (!has_next) break;
         it = next;
@@ -1258,29 +1276,64 @@ void launch_fixup(const GemmParams& p, int splits, hipStream_t stream) {
                        (int64_t)p.M * p.N);
 }
 
-template <typename T, int NT>
-bool launch_gemm_pp(const GemmParams& p, hipStream_t stream) {
-    if (!pp_eligible(NT, p)) return false;
+template <typename T, int NT, int MI>
+void launch_pp_tiles(const GemmParams& p, int splits, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, pp::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<T, NT, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, pp::LDS_BYTES);
         attr_set = true;
     }
-    const int tiles = ((p.N + pp::BN - 1) / pp::BN) * ((p.M + pp::BM - 1) / pp::BM);
+    const int tiles = ((p.N + pp::BN - 1) / pp::BN) * ((p.M + MI * 32 - 1) / (MI * 32));
     const int cus = device_cus();
-    // main-loop length of a tile in MFMA segments: long loops (K = 4096, or 1536 with split planes) are cut when half the
-    // chip would idle, 1024-deep split-plane loops only when three quarters would; 1024-deep single-plane loops never
-    const int weight = p.K * (NT > 1 ? 3 : 1);
-    const int max_tiles = weight >= 4096 ? cus / 2 : (weight >= 3072 ? cus / 4 : 0);
-    const int splits = choose_splits(p, tiles, max_tiles, 128, 256);
     const int units = tiles * splits;
     dim3 grid(units < cus ? units : cus, 1, 1);  // persistent: one 128-KiB-LDS workgroup per CU
     if (splits > 1) {
-        hipLaunchKernelGGL((gemm_pp_kernel<T, NT>), grid, dim3(512), pp::LDS_BYTES, stream, split_view(p, splits));
+        hipLaunchKernelGGL((gemm_pp_kernel<T, NT, MI>), grid, dim3(512), pp::LDS_BYTES, stream, split_view(p, splits));
         launch_fixup<T, NT>(p, splits, stream);
     } else {
-        hipLaunchKernelGGL((gemm_pp_kernel<T, NT>), grid, dim3(512), pp::LDS_BYTES, stream, p);
+        hipLaunchKernelGGL((gemm_pp_kernel<T, NT, MI>), grid, dim3(512), pp::LDS_BYTES, stream, p);
     }
+}
+
+// Tile height (256 or 128 rows) and number of K chunks of a ping-pong product, by a cost model in units of one 32-deep MFMA
+// segment pair per K element (~ 0.0166 us; fitted to tools/gemm_bench `small` on MI355X):
+//   rounds of the persistent grid x (main loop of a work unit + its prologue / epilogue) + fix-up launch and slab traffic.
+// Config-2-sized products (>= one full round of 256-row tiles) always come out as (256 rows, 1 chunk).
+void pp_plan(int NT, const GemmParams& p, int* mi_out, int* splits_out) {
+    const int cus = device_cus();
+    const double loop = (double)p.K * (NT > 1 ? 3 : 1);  // main loop of a 256-row tile
+    double best = 1e30;
+    *mi_out = 8;
+    *splits_out = 1;
+    for (int mi = 8; mi >= 4; mi -= 4) {
+        const int tiles = ((p.N + pp::BN - 1) / pp::BN) * ((p.M + mi * 32 - 1) / (mi * 32));
+        const double per_unit = 480.0 + 60.0 * mi;  // prologue + epilogue of a work unit
+        int64_t smax = 1;
+        if (p.splitk_ws && p.K % 128 == 0) {
+            smax = std::min<int64_t>(p.K / 256, p.splitk_ws_elems / ((int64_t)p.M * p.N));
+            smax = std::min<int64_t>(smax, 32);
+        }
+        for (int sp = 1; sp <= smax; ++sp) {
+            if ((p.K / 128) % sp) continue;
+            const int64_t units = (int64_t)tiles * sp;
+            double cost = (double)((units + cus - 1) / cus) * (loop * mi / 8.0 / sp + per_unit);
+            if (sp > 1) cost += 700.0 + (double)sp * p.M * p.N * 8.0 / 4.0e6 / 0.0166;  // fix-up launch + slab write / read at 4 TB/s
+            if (cost < best * 0.97) {  // prefer the earlier candidate (taller tile, fewer chunks) on near ties
+                best = cost;
+                *mi_out = mi;
+                *splits_out = sp;
+            }
+        }
+    }
+}
+
+template <typename T, int NT>
+bool launch_gemm_pp(const GemmParams& p, hipStream_t stream) {
+    if (!pp_eligible(NT, p)) return false;
+    int mi, splits;
+    pp_plan(NT, p, &mi, &splits);
+    if (mi == 8) launch_pp_tiles<T, NT, 8>(p, splits, stream);
+    else launch_pp_tiles<T, NT, 4>(p, splits, stream);
     return true;
 }
 

@@ -283,6 +283,11 @@ int main(int argc, char** argv) {
             {"conv-like overlapping rows", 2800, 512, 384, 0, 0, 0, 0, 1, 0, 700, 256, 1.0f},
             {"qkv scatter", 1497, 384, 256, 0, 0, 0, 0, 0, 1, 0, 0, 1.0f},
             {"long K", 1100, 256, 4096, 0, 1, 0, 0, 1, 0, 0, 0, 1.0f},
+            // enough tiles for the 256 x 256 kernel (the cases above run on 128 x 256 tiles)
+            {"256-row tiles f32 +res +mask", 16000, 1024, 256, 0, 1, 1, 0, 1, 0, 0, 0, 1.0f},
+            {"256-row tiles gelu->planes, M tail", 15968, 2048, 128, 1, 0, 0, 1, 0, 0, 0, 0, 1.0f},
+            {"256-row tiles qkv scatter", 15968, 3072, 256, 0, 0, 0, 0, 0, 1, 0, 0, 1.0f},
+            {"256-row tiles conv-like", 31996, 512, 1536, 0, 0, 0, 0, 1, 0, 7999, 1024, 1.0f},
             // split-K (few tiles): ping-pong kernel with K chunks, generic kernel with grid.z chunks, + fix-up epilogue
             {"split pp gelu->planes", 2000, 1024, 1024, 1, 0, 0, 1, 0, 0, 0, 0, 1.0f},
             {"split pp qkv scatter", 1996, 3072, 1024, 0, 0, 0, 0, 0, 1, 0, 0, 1.0f},
