@@ -1192,10 +1192,13 @@ void launch_gemm_ln(const GemmParams& p, hipStream_t stream) {
     hipLaunchKernelGGL((gemm_ln_kernel<T, NT>), grid, dim3(512), ppw::LDS_BYTES, stream, p);
 }
 
+// below this many rows the 128 x 128 tile kernel with K chunks on grid.z is as fast (tools/gemm_bench `small`)
+constexpr int PP_MIN_ROWS = 384;
+
 bool pp_eligible(int NT, const GemmParams& p) {
     // eligibility: whole sub-step groups, aligned operand rows and vector epilogue, enough rows to fill the chip
     if (g_force_generic_gemm) return false;
-    if (p.K % (128 / NT) != 0 || p.N < 256 || p.N % 4 != 0 || p.M < 1024) return false;
+    if (p.K % (128 / NT) != 0 || p.N < 256 || p.N % 4 != 0 || p.M < PP_MIN_ROWS) return false;
     if (p.lda % 8 || p.ldw % 8 || p.a_plane % 8 || p.w_plane % 8 || p.a_batch_stride % 8) return false;
     if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return false;
     // DMA addressing: 32-bit byte offsets from the tile's first row; rows of a tile ascend in memory

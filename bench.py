@@ -43,7 +43,7 @@ def build_spec():
 def gemm_flops(spec, n, length, planes):
     """Algorithmic FLOPs per step of the launches of each GEMM kernel (SURVEY.md Appendix D formulas).  The routing rule
     mirrors ``pp_eligible`` in allophant_amd/csrc/amx_gemm.hip: the 256 x 256 ping-pong kernel takes every product with
-    N >= 256, N % 4 == 0, M >= 1024 and K a multiple of 128 / planes; the generic tile kernel takes the rest."""
+    N >= 256, N % 4 == 0, M >= 384 and K a multiple of 128 / planes; the generic tile kernel takes the rest."""
     C, D, F = spec["conv_dim"], spec["hidden"], spec["ffn"]
     ts = [length]
     for k, s in zip(spec["conv_kernel"], spec["conv_stride"]):
@@ -73,7 +73,7 @@ def gemm_flops(spec, n, length, planes):
     b16 = 2 * planes
     for idx, (m, nn, k, cnt) in enumerate(products):
         fl = 2 * m * nn * k * cnt
-        if nn >= 256 and nn % 4 == 0 and m >= 1024 and k % (128 // planes) == 0:
+        if nn >= 256 and nn % 4 == 0 and m >= 384 and k % (128 // planes) == 0:
             pp += fl
             pp_launches += cnt
             a_bytes = m * k * b16
