@@ -226,8 +226,8 @@ def main():
         gemm_ms, gemm_launches = timing["gemm_pp"]
         achieved = fl["gemm_pp"] * steps / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else None
         return fl, frames_per_rank, {
-            "kernel": "gemm_pp_kernel<T16, planes>: persistent 256x256 ping-pong GEMM (last conv layer, feature projection, "
-                      "QKV / out-proj / FFN of the 24 encoder layers, phoneme head)",
+            "kernel": "gemm_pp_kernel<T16, planes, MI>: persistent ping-pong GEMM, 256x256 tiles (MI = 8: feature projection, "
+                      "QKV / out-proj / FFN of the 24 encoder layers, phoneme head) or 128x256 (MI = 4: last conv layer)",
             "bound": "mfma",
             "achieved": achieved,
             "peak": MFMA_PEAK_TFLOPS,
