@@ -441,3 +441,28 @@ def test_random_models_and_geometries_against_oracle(amd, seed):
             assert pred.outputs[k].shape == ref[k].shape, k
             assert max_abs_valid_tm(pred.outputs[k].cpu(), ref[k], ref_len) < GATE, (seed, geometry, k)
     est.close()
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "bf16x3"])
+def test_long_utterances(amd, precision):
+    """A 25 s utterance (20 key tiles per query block) next to 9 s and 1.3 s ones against the oracle, with the encoder
+    hidden states checked too."""
+    from oracle import allophant_oracle as O
+
+    spec = S.multitask_spec(S.tiny_encoder(2), ["syllabic", "long"], embedding_size=16, train_phonemes=9, n_features=5)
+    state = synthetic.make_state_dict(spec, seed=12)
+    tfi = synthetic.make_inventory(spec, 7, seed=2)
+    audio, lengths = synthetic.make_audio(3, 400000, seed=99)
+    lengths[1], lengths[2] = 150000, 20800
+    audio[1, 150000:] = 0
+    audio[2, 20800:] = 0
+    est = amd.Estimator(spec, state, "cuda:0", precision)
+    pred = est.predict(amd.Batch(audio.cuda(), lengths, torch.zeros(3, dtype=torch.long)), tfi, _keep_hidden=True)
+    ref, ref_len, inter = O.predict(audio, lengths, state, spec, tfi, synthetic.category_offsets(spec), True,
+                                    keep_intermediates=True)
+    assert ref_len.tolist() == [1249, 468, 64] and torch.equal(pred.lengths.cpu(), ref_len)
+    for i in range(3):
+        assert max_abs_valid_bm(est.debug_fetch("hidden", i), inter["hidden_states"][i], ref_len) < GATE, i
+    for k in ref:
+        assert max_abs_valid_tm(pred.outputs[k].cpu(), ref[k], ref_len) < GATE, k
+    est.close()
