@@ -51,8 +51,8 @@ extern "C" {
 #define AMX_FLAG_TIMING 8u       /* bracket every kernel launch with HIP events on the launch stream (amx_timing_fetch) */
 
 /* kernel classes reported by amx_timing_fetch */
-#define AMX_KC_GEMM_PP 0   /* gemm_pp_kernel<T, NT>: 256x256 ping-pong GEMM -- conv layer 6, feature projection, QKV/out/FFN, wide heads */
-#define AMX_KC_GEMM_TILE 1 /* gemm_kernel<T, NT, 128, {128,64}>: grouped positional conv, narrow heads, shapes the 256x256 kernel rejects */
+#define AMX_KC_GEMM_PP 0   /* gemm_pp_kernel<T, NT, MI>: ping-pong GEMM on 256x256 / 128x256 tiles -- last conv layer, feature projection, QKV/out/FFN, wide heads */
+#define AMX_KC_GEMM_TILE 1 /* gemm_kernel<T, NT, 128, {128,64}>: grouped positional conv, narrow heads, shapes the ping-pong kernel rejects */
 #define AMX_KC_ATTENTION 2
 #define AMX_KC_ROWNORM 3
 #define AMX_KC_CONV0 4
