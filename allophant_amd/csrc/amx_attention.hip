@@ -52,9 +52,17 @@ __global__ __launch_bounds__(WAVES * 64, AMX_ATTN_OCC) void attn_kernel(const At
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hh = lane >> 5, lq = lane & 31;
-    const int nh = blockIdx.y;
+    // XCD-aware order (1-D grid): workgroups are dealt round-robin over the 8 XCDs, so the query blocks of one (utterance,
+    // head) are given consecutive slots of ONE XCD: they run side by side and the K / V tiles one of them pulls into that
+    // XCD's L2 serve the others (with the plain (query block, head) grid every query block re-read K and V from HBM, and
+    // the kernel was bound by that traffic).  Pure speed: any placement gives the same results.
+    const int qblocks = (p.T + QB - 1) / QB;
+    const int slot = blockIdx.x >> 3;
+    const int nh = (slot / qblocks) * 8 + (blockIdx.x & 7);
+    const int qblock = slot % qblocks;
+    if (nh >= p.N * p.H) return;
     const int n = nh / p.H, h = nh % p.H;
-    const int q_base = blockIdx.x * QB + wave * 32;
+    const int q_base = qblock * QB + wave * 32;
     const int query = q_base + lq;
     int klen = p.frame_len[n];
     klen = klen < 1 ? 1 : (klen > p.T ? p.T : klen);
@@ -262,7 +270,8 @@ void launch_attn(const AttnParams& p, hipStream_t stream) {
         (void)hipFuncSetAttribute((const void*)attn_kernel<T, NT, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    dim3 grid((p.T + WAVES * 32 - 1) / (WAVES * 32), p.N * p.H);
+    const int qblocks = (p.T + WAVES * 32 - 1) / (WAVES * 32);
+    dim3 grid((unsigned)(8 * ((p.N * p.H + 7) / 8) * qblocks));
     hipLaunchKernelGGL((attn_kernel<T, NT, WAVES>), grid, dim3(WAVES * 64), lds, stream, p);
 }
 
