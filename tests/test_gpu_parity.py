@@ -402,6 +402,10 @@ def _random_spec(rng):
         rng.shuffle(deps)
         c["dependencies"] = deps
         if rng.integers(0, 4) == 0:
+            # a time layer normalises over the class width: with 2 channels LayerNorm maps (a, b) to +-1 / sqrt(1 + 4 eps /
+            # (a - b)^2), which amplifies fp32 rounding of a - b without bound (seeds 134 and 261 of a 300-seed run landed
+            # at 1.2e-3 / 2.1e-3 on such a head); attribute classes have 4 channels upstream
+            c["size"] = max(c["size"], 2)
             width = c["size"] + 1
             heads = int(rng.choice([h for h in (1, 2, 3) if width % h == 0]))
             c["time_layer"] = {"num_heads": heads, "positional_embeddings": bool(width % 2 == 0 and rng.integers(0, 2))}
@@ -412,7 +416,7 @@ def _random_spec(rng):
     return spec
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AMX_RANDOM_SEEDS", "8"))))
 def test_random_models_and_geometries_against_oracle(amd, seed):
     """Randomised classifier graphs, inventories and ragged batch geometries (1-6 utterances of 400-20 000 samples,
     including single-frame utterances) against the CPU oracle, in the parity mode."""
@@ -429,7 +433,7 @@ def test_random_models_and_geometries_against_oracle(amd, seed):
         audio, lengths = synthetic.make_audio(n, length, seed=seed * 10 + geometry, ragged=True)
         lengths = torch.clamp(lengths, min=400)
         if n > 1 and rng.integers(0, 2):
-            lengths[-1] = 400 + int(rng.integers(0, 320))  # one or two output frames
+            lengths[-1] = min(length, 400 + int(rng.integers(0, 320)))  # one or two output frames
         for i in range(n):
             audio[i, int(lengths[i]):] = 0
         tfi = synthetic.make_inventory(spec, int(rng.integers(1, 15)), seed=seed + geometry) if composed else None
