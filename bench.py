@@ -166,7 +166,7 @@ def main():
     audio, lengths = synthetic.make_audio(n, length, seed=1234 + rank)
 
     def measure(precision, steps, warmup):
-        """K timed steps (no per-kernel events: recording ~380 events costs ~1.2 ms per step) bracketed by barrier +
+        """K timed steps (no per-kernel events: recording ~370 events costs 0.3-1.2 ms per step) bracketed by barrier +
         synchronize, then a second pass of K steps with HIP events around every launch for the per-kernel numbers."""
         est = Estimator(spec, state, device, precision)
         batch = Batch(audio.to(device), lengths, torch.zeros(n, dtype=torch.long))
@@ -247,7 +247,7 @@ def main():
                 "achieved": fl["gemm_ln"] * steps / (timing["gemm_ln"][0] * 1e-3) / 1e12 if timing["gemm_ln"][0] > 0 else None,
                 "avg_launch_ms": timing["gemm_ln"][0] / timing["gemm_ln"][1] if timing["gemm_ln"][1] else None,
             },
-            "timing": "HIP events around every launch in a second pass of the same K steps (recording them costs ~1.2 ms per "
+            "timing": "HIP events around every launch in a second pass of the same K steps (recording them costs 0.3-1.2 ms per "
                       "step, so the timed region that yields `value` runs without them)",
         }
 
