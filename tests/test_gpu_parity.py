@@ -470,3 +470,25 @@ def test_long_utterances(amd, precision):
     for k in ref:
         assert max_abs_valid_tm(pred.outputs[k].cpu(), ref[k], ref_len) < GATE, k
     est.close()
+
+
+@pytest.mark.parametrize("utterances,seconds", [(1, 3.0), (4, 10.0)])
+def test_outputs_are_bitwise_reproducible(amd, utterances, seconds):
+    """No atomics anywhere on the path (split-K partials are reduced in slab order): repeated calls, a second handle and
+    a different batch position give bit-identical log-probabilities at XLS-R shape (short batches exercise the 128-row
+    tiles, the K chunks and the fix-up epilogue)."""
+    spec = S.multitask_spec(S.xlsr_300m_encoder(), allophone_layer=True)
+    spec["shared_phones"] = 80
+    state = synthetic.make_state_dict(spec, seed=0)
+    tfi = synthetic.make_inventory(spec, 27, seed=0)
+    audio, lengths = synthetic.make_audio(utterances, int(seconds * 16000), seed=5, ragged=True)
+    batch = amd.Batch(audio.cuda(), lengths, torch.zeros(utterances, dtype=torch.long))
+    est = amd.Estimator(spec, state, "cuda:0", "f16x3")
+    first = est.predict(batch, tfi)
+    for _ in range(3):
+        again = est.predict(batch, tfi)
+        assert torch.equal(again._flat, first._flat)
+    other = amd.Estimator(spec, state, "cuda:0", "f16x3")
+    assert torch.equal(other.predict(batch, tfi)._flat, first._flat)
+    other.close()
+    est.close()
