@@ -160,3 +160,27 @@ def test_batch_and_predictions_containers():
     assert isinstance(moved, Batch) and moved.audio_features.shape == (3, 10)
     p = Predictions({"a": torch.zeros(2, 3, 4)}, torch.tensor([2, 1, 2]))
     assert len(p) == 3 and p.task_count() == 1
+
+
+def test_mask_and_length_helpers_match_reference_goldens():
+    """``mask_sequence`` / ``downsampled_lengths`` (reference utils.py:45-76, acoustic_model.py:832-835) against the integer
+    goldens recorded from the reference (g4) and the spec-level frame formula."""
+    import numpy as np
+
+    from allophant_amd import utils
+
+    z = np.load(os.path.join(ROOT, "tests", "golden", "g4_integer.npz"))
+    spec = S.xlsr_300m_encoder()
+    samples = torch.from_numpy(z["lengths_in"])
+    frames = utils.downsampled_lengths(samples, spec["conv_kernel"], spec["conv_stride"])
+    assert torch.equal(frames, torch.from_numpy(z["lengths_out"]))
+    assert frames.tolist() == S.frame_lengths(samples.tolist(), spec)
+    recorded = torch.from_numpy(z["mask_lengths"])
+    assert torch.equal(utils.mask_sequence(recorded), torch.from_numpy(z["mask"]).bool())  # the reference's own mask
+    lengths = torch.tensor([5, 2, 7])
+    mask = utils.mask_sequence(lengths)
+    assert mask.shape == (3, 7) and mask.sum(1).tolist() == [5, 2, 7] and bool(mask[1, 1]) and not bool(mask[1, 2])
+    assert torch.equal(utils.mask_sequence(lengths, inverse=True), ~mask)
+    assert torch.equal(utils.mask_sequence(lengths, batch_first=False), mask.t())
+    assert utils.mask_sequence(lengths, max_length=4).shape == (3, 4)
+    assert utils.mask_sequence(lengths, max_length=9, start=2).shape == (3, 7)
