@@ -10,6 +10,7 @@
 //   positional convolution are implicit GEMMs over channels-last activations, no im2col buffer.
 #include "amx_common.h"
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 namespace amx {
@@ -261,6 +262,149 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
     }
 
     // ---- epilogue ----
+    gemm_epilogue<T, NT, MI, NI>(p, z, acc, m0 + wm * TM, n0 + wn * TN, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-DMA variant of the tile kernel: the same fragment layout, products and epilogue as gemm_kernel, but the operand
+// tiles go global -> LDS with buffer_load_dwordx4 ... lds into a ring of STAGES stages, STAGES - 1 K tiles ahead of the
+// MFMAs (gemm_kernel stages one K tile through registers and exposes a memory round trip per tile, which is what short
+// products -- single utterances, narrow heads -- spend their time on).  One s_barrier per K tile:
+//   iteration t: wait for tile t (this wave's pieces), barrier, issue the DMA of tile t + STAGES - 1 into the stage tile
+//   t - 1 was read from (every wave finished those reads before the barrier), multiply tile t.
+// Two shapes, 4 waves each: 128 x 64 (waves 4 x 1, 3 stages) and 64 x 32 (waves 2 x 2, 6 stages: more workgroups and a
+// deeper ring for the shortest products, which are bound by how many bytes the chip keeps in flight).
+// The LDS image of a DMA is lane-linear, so the bank swizzle of lds_off() sits on the per-lane SOURCE address.
+// Requires K % 64 == 0, 16-byte aligned operand rows, 32-bit byte offsets inside a tile.
+// ---------------------------------------------------------------------------------------------------------------
+template <int N_OUTSTANDING>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_OUTSTANDING) : "memory");
+}
+
+template <typename T, int NT, int BM, int BN, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmParams p) {
+    typedef typename Vec8<T>::type V8;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    static_assert(WM * WN == 4 && BM % (32 * 1) == 0 && BN % 32 == 0, "4 waves, whole DMA pieces per wave");
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int MI = TM / 16, NI = TN / 16;
+    constexpr int APW = BM / 32, WPW = BN / 32;   // DMA pieces (8 rows x 128 B) per wave, K tile and plane
+    constexpr int PLANE = (BM + BN) * 128;         // bytes of one plane of one stage: A rows then W rows, 128 B (64 k) each
+    constexpr int STAGE = NT * PLANE;
+    constexpr int PPT = NT * (APW + WPW);          // DMA instructions per wave and K tile
+    constexpr int AHEAD = STAGES - 1;
+    static_assert(AHEAD * PPT < 64, "vmcnt range");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int z = blockIdx.z;
+    const T* A = (const T*)p.A + (int64_t)z * p.za;
+    const T* W = (const T*)p.W + (int64_t)z * p.zw;
+
+    // ---- DMA state: SGPR descriptors at the tile's first rows + 32-bit per-lane byte offsets ----
+    const int m0c = m0 < p.M ? m0 : p.M - 1, n0c = n0 < p.N ? n0 : p.N - 1;
+    const int64_t b0 = m0c / p.rows_per_batch;
+    const int64_t a_tile = b0 * p.a_batch_stride + (m0c - b0 * p.rows_per_batch) * p.lda;
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(A + a_tile), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (int64_t)n0c * p.ldw), 0, -1, 0x00020000);
+    // fixed bounds: hipcc 7.2 silently drops the host stub of a kernel template whose called lambda captures an array
+    // whose bound depends on a template parameter
+    static_assert(APW <= 4 && WPW <= 2, "offset arrays");
+    uint32_t a_off[4], w_off[2];
+#pragma unroll
+    for (int j = 0; j < APW; ++j) {
+        const int row = (wave * APW + j) * 8 + (lane >> 3);
+        const int lc = (lane & 7) ^ ((row >> 1) & 7);  // logical 16-byte chunk stored at physical chunk lane & 7
+        int rr = m0 + row;
+        rr = rr < p.M ? rr : p.M - 1;
+        const int64_t b = rr / p.rows_per_batch;
+        const int64_t t = rr - b * p.rows_per_batch;
+        a_off[j] = (uint32_t)((b * p.a_batch_stride + t * p.lda - a_tile + lc * 8) * 2);
+    }
+#pragma unroll
+    for (int j = 0; j < WPW; ++j) {
+        const int row = (wave * WPW + j) * 8 + (lane >> 3);
+        const int lc = (lane & 7) ^ ((row >> 1) & 7);
+        int rn = n0 + row;
+        rn = rn < p.N ? rn : p.N - 1;
+        w_off[j] = (uint32_t)(((int64_t)(rn - n0c) * p.ldw + lc * 8) * 2);
+    }
+    const uint32_t a_plane_b = (uint32_t)(p.a_plane * 2), w_plane_b = (uint32_t)(p.w_plane * 2);
+    auto stage = [&](int kt, int st) {
+        unsigned char* base = smem + st * STAGE;
+#pragma unroll
+        for (int pl = 0; pl < NT; ++pl) {
+            const uint32_t so_a = pl * a_plane_b + (uint32_t)kt * 128, so_w = pl * w_plane_b + (uint32_t)kt * 128;
+            unsigned char* dst = base + pl * PLANE;
+#pragma unroll
+            for (int j = 0; j < APW; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_ptr_t)(dst + (wave * APW + j) * 1024), 16, a_off[j], so_a, 0, 0);
+#pragma unroll
+            for (int j = 0; j < WPW; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(dst + BM * 128 + (wave * WPW + j) * 1024), 16,
+                                                         w_off[j], so_w, 0, 0);
+        }
+    };
+    // waits until at most the pieces of `tiles_ahead` later K tiles are still in flight (wave-uniform run-time count)
+    auto wait_tile = [](int tiles_ahead) {
+        switch (tiles_ahead) {
+            case 0: wait_vmcnt<0>(); break;
+            case 1: wait_vmcnt<PPT>(); break;
+            case 2: wait_vmcnt<(AHEAD >= 2 ? 2 : 0) * PPT>(); break;
+            case 3: wait_vmcnt<(AHEAD >= 3 ? 3 : 0) * PPT>(); break;
+            case 4: wait_vmcnt<(AHEAD >= 4 ? 4 : 0) * PPT>(); break;
+            default: wait_vmcnt<(AHEAD >= 5 ? 5 : 0) * PPT>(); break;
+        }
+    };
+    static_assert(AHEAD <= 6, "wait_tile covers up to 5 tiles ahead");
+
+    f32x4 acc[NI][MI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    for (int t = 0; t < AHEAD && t < nk; ++t) stage(t, t);
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt has landed once only the tiles issued after it (kt + 1 .. kt + AHEAD - 1) may still be in flight
+        const int later = nk - 1 - kt;
+        wait_tile(later < AHEAD - 1 ? later : AHEAD - 1);
+        __builtin_amdgcn_s_barrier();
+        if (kt + AHEAD < nk) stage(kt + AHEAD, (kt + AHEAD) % STAGES);
+        const unsigned char* sb = smem + (kt % STAGES) * STAGE;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int c = 4 * s2 + (lane >> 4);
+            V8 af[NT][MI], wf[NT][NI];
+#pragma unroll
+            for (int pl = 0; pl < NT; ++pl) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    af[pl][mi] = *(const V8*)(sb + pl * PLANE + lds_off(wm * TM + mi * 16 + (lane & 15), c));
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    wf[pl][ni] = *(const V8*)(sb + pl * PLANE + BM * 128 + lds_off(wn * TN + ni * 16 + (lane & 15), c));
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    if (NT > 1) {
+                        acc[ni][mi] = mfma16(wf[NT - 1][ni], af[0][mi], acc[ni][mi]);  // lo(W) * hi(A)
+                        acc[ni][mi] = mfma16(wf[0][ni], af[NT - 1][mi], acc[ni][mi]);  // hi(W) * lo(A)
+                    }
+                    acc[ni][mi] = mfma16(wf[0][ni], af[0][mi], acc[ni][mi]);
+                }
+        }
+        // this wave's reads of the stage are complete before it can pass the next barrier
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     gemm_epilogue<T, NT, MI, NI>(p, z, acc, m0 + wm * TM, n0 + wn * TN, lane);
 }
 
@@ -1340,14 +1484,75 @@ bool launch_gemm_pp(const GemmParams& p, hipStream_t stream) {
     return true;
 }
 
+bool dma_tile_eligible(int NT, const GemmParams& p) {
+    static const bool off = getenv("AMX_NO_DMA_TILE") && atoi(getenv("AMX_NO_DMA_TILE")) != 0;  // developer A/B switch
+    if (off || p.K % BK != 0) return false;
+    if (p.lda % 8 || p.ldw % 8 || p.a_plane % 8 || p.w_plane % 8 || p.a_batch_stride % 8 || p.za % 8 || p.zw % 8) return false;
+    if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return false;
+    // rows of a tile ascend in memory and stay inside 32-bit byte offsets from the tile's first row
+    if (p.M > p.rows_per_batch && p.a_batch_stride < (p.rows_per_batch - 1) * p.lda) return false;
+    const int64_t batches_per_tile = p.M > p.rows_per_batch ? (128 + p.rows_per_batch - 1) / p.rows_per_batch + 1 : 0;
+    const int64_t a_span = (NT > 1 ? p.a_plane : 0) + batches_per_tile * p.a_batch_stride + 128 * p.lda + p.K;
+    const int64_t w_span = (NT > 1 ? p.w_plane : 0) + 64 * p.ldw + p.K;
+    if (a_span < 0 || w_span < 0 || a_span * 2 >= (int64_t)0xFFFFFF00 || w_span * 2 >= (int64_t)0xFFFFFF00) return false;
+    return true;
+}
+
+// the LDS-DMA kernel holds one workgroup per CU (144 KiB ring): it serves the short products, big grids keep the
+// register-staged kernel (several workgroups per CU).  Returns the tile shape: 0 = not used, 1 = 128 x 64, 2 = 64 x 32.
+int dma_tile_shape(int NT, const GemmParams& p, int zdim) {
+    if (!dma_tile_eligible(NT, p)) return 0;
+    const int64_t big = (int64_t)((p.N + 63) / 64) * ((p.M + 127) / 128) * zdim;
+    if (big > device_cus()) return 0;
+    return big * 2 <= device_cus() ? 2 : 1;
+}
+
+template <typename T, int NT, int BM, int BN, int WM, int WN, int STAGES>
+void launch_gemm_dma(const GemmParams& q, int zdim, hipStream_t stream) {
+    constexpr int lds = STAGES * NT * (BM + BN) * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<T, NT, BM, BN, WM, WN, STAGES>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    dim3 grid((q.N + BN - 1) / BN, (q.M + BM - 1) / BM, zdim);
+    hipLaunchKernelGGL((gemm_dma_kernel<T, NT, BM, BN, WM, WN, STAGES>), grid, dim3(256), lds, stream, q);
+}
+
+template <typename T, int NT>
+void launch_gemm_dma_shape(int shape, const GemmParams& q, int zdim, hipStream_t stream) {
+    if (shape == 2) launch_gemm_dma<T, NT, 64, 32, 2, 2, 6>(q, zdim, stream);
+    else launch_gemm_dma<T, NT, 128, 64, 4, 1, 3>(q, zdim, stream);
+}
+
 template <typename T, int NT>
 void launch_gemm_t(const GemmParams& p, hipStream_t stream) {
-    if (launch_gemm_pp<T, NT>(p, stream)) return;
+    // below ~768 rows a product that fits one round of LDS-DMA tiles is faster there than on 128-row ping-pong tiles
+    // (tools/geometry_sweep.py: 1 x 10 s 5.5 -> 4.0 ms); everything else the ping-pong kernel accepts goes to it
+    const int shape = dma_tile_shape(NT, p, 1);
+    if (!(shape && p.M < 768) && launch_gemm_pp<T, NT>(p, stream)) return;
+    if (shape) {
+        // the ring hides the memory latency, so the K loop is only cut where it is long (K = 4096) and the grid small
+        const int bm = shape == 2 ? 64 : 128, bn = shape == 2 ? 32 : 64;
+        const int tiles = ((p.N + bn - 1) / bn) * ((p.M + bm - 1) / bm);
+        const int splits = p.K >= 4096 ? choose_splits(p, tiles, device_cus() / 2, BK, 16 * BK) : 1;
+        GemmParams q = p;
+        if (splits > 1) {
+            q = split_view(p, splits);
+            q.za = q.zw = q.K;
+            q.zout = q.split_out;
+            q.zbias = q.zoutp = 0;
+        }
+        launch_gemm_dma_shape<T, NT>(shape, q, splits, stream);
+        if (splits > 1) launch_fixup<T, NT>(p, splits, stream);
+        return;
+    }
     // narrow outputs (grouped pos-conv, small classifier heads) use the 128x64 tile
     const bool narrow = p.N <= 64;
     const int BM = 128, BN = narrow ? 64 : 128;
     const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
-    // short products (a single utterance, the late conv layers): the K loop of a tile is latency-bound, so cut it
+    // short products whose shape the LDS-DMA kernel rejects: the K loop of a register-staged tile is latency-bound, so cut it
     const int splits = choose_splits(p, tiles, device_cus() / 4, BK, 2 * BK);
     GemmParams q = p;
     if (splits > 1) {
@@ -1365,6 +1570,11 @@ void launch_gemm_t(const GemmParams& p, hipStream_t stream) {
 
 template <typename T, int NT>
 void launch_gemm_z(const GemmParams& p, int zdim, hipStream_t stream) {
+    const int shape = dma_tile_shape(NT, p, zdim);
+    if (shape) {
+        launch_gemm_dma_shape<T, NT>(shape, p, zdim, stream);
+        return;
+    }
     constexpr int BM = 128, BN = 64;
     dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, zdim);
     size_t lds = (size_t)NT * (BM + BN) * 128;
@@ -1384,7 +1594,11 @@ static GemmParams with_vec_flag(const GemmParams& in) {
 
 bool gemm_fuses_ln(int prec, const GemmParams& p_in) { return ln_eligible(prec_planes(prec), with_vec_flag(p_in)); }
 
-bool gemm_uses_pp(int prec, const GemmParams& p_in) { return pp_eligible(prec_planes(prec), with_vec_flag(p_in)); }
+bool gemm_uses_pp(int prec, const GemmParams& p_in) {
+    const GemmParams p = with_vec_flag(p_in);
+    const int NT = prec_planes(prec);
+    return pp_eligible(NT, p) && !(p.M < 768 && dma_tile_shape(NT, p, 1));  // the routing of launch_gemm_t
+}
 
 void launch_gemm(int prec, const GemmParams& p_in, hipStream_t stream) {
     const GemmParams p = with_vec_flag(p_in);
