@@ -70,7 +70,7 @@ __global__ void audio_stats_final_kernel(const double* __restrict__ partial, con
 // One wave per output frame, lane owns CPL consecutive channels (weights in registers), window staged in LDS.
 // HBM-bound: reads 4 B/sample once, writes 2*NT bytes per output element.
 // ----------------------------------------------------------------------------------------------------------------
-constexpr int C0_FRAMES = 64;
+constexpr int C0_FRAMES = 128;  // frames per workgroup: amortises the per-lane weight loads
 
 template <typename T, int NT, int CPL, int KW>
 __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ audio, const int64_t* __restrict__ lengths,
@@ -99,20 +99,128 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ au
     const int c0 = lane * CPL;
     const bool active = c0 < C;
     float wr[CPL][KW], br[CPL], gr[CPL], be[CPL];
+    if ((CPL * KW) % 4 == 0 && k == KW && c0 + CPL <= C) {
+        // this lane's CPL x KW weights are contiguous and 16-byte aligned: branch-free vector loads (the per-element
+        // predicated loads of the general path cost as much as the block's arithmetic)
+        float flat[CPL * KW];
+        const float4* src = (const float4*)(w + (int64_t)c0 * KW);
 #pragma unroll
-    for (int i = 0; i < CPL; ++i) {
-        int c = c0 + i;
-        bool ok = c < C;
+        for (int q = 0; q < CPL * KW / 4; ++q) {
+            const float4 v = src[q];
+            flat[4 * q] = v.x; flat[4 * q + 1] = v.y; flat[4 * q + 2] = v.z; flat[4 * q + 3] = v.w;
+        }
 #pragma unroll
-        for (int j = 0; j < KW; ++j) wr[i][j] = (ok && j < k) ? w[c * k + j] : 0.f;
-        br[i] = ok ? b[c] : 0.f;
-        gr[i] = ok ? gamma[c] : 0.f;
-        be[i] = ok ? beta[c] : 0.f;
+        for (int i = 0; i < CPL; ++i) {
+#pragma unroll
+            for (int j = 0; j < KW; ++j) wr[i][j] = flat[i * KW + j];
+            br[i] = b[c0 + i];
+            gr[i] = gamma[c0 + i];
+            be[i] = beta[c0 + i];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            int c = c0 + i;
+            bool ok = c < C;
+#pragma unroll
+            for (int j = 0; j < KW; ++j) wr[i][j] = (ok && j < k) ? w[c * k + j] : 0.f;
+            br[i] = ok ? b[c] : 0.f;
+            gr[i] = ok ? gamma[c] : 0.f;
+            be[i] = ok ? beta[c] : 0.f;
+        }
     }
     __syncthreads();
     const float invC = 1.0f / (float)C;
     // two frames per wave iteration: the two dependent chains (conv -> mean -> variance -> GELU) interleave
     constexpr int FPI = 2;
+    if constexpr (CPL % 2 == 0) {
+        // channel pairs on the packed fp32 pipe (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32, packed 16-bit converts): the
+        // kernel is VALU-bound, and this halves the instructions of the convolution, the normalisation and the split
+        typedef typename Vec2<T>::type V2;
+        constexpr int CP = CPL / 2;
+        f32x2 w2[CP][KW], b2[CP], g2[CP], be2[CP];
+#pragma unroll
+        for (int i = 0; i < CP; ++i) {
+#pragma unroll
+            for (int j = 0; j < KW; ++j) w2[i][j] = f32x2{wr[2 * i][j], wr[2 * i + 1][j]};
+            b2[i] = f32x2{br[2 * i], br[2 * i + 1]};
+            g2[i] = f32x2{gr[2 * i], gr[2 * i + 1]};
+            be2[i] = f32x2{be[2 * i], be[2 * i + 1]};
+        }
+        for (int f = wave * FPI; f < C0_FRAMES; f += 4 * FPI) {
+            f32x2 acc[FPI][CP];
+#pragma unroll
+            for (int u = 0; u < FPI; ++u)
+#pragma unroll
+                for (int i = 0; i < CP; ++i) acc[u][i] = b2[i];
+#pragma unroll
+            for (int j = 0; j < KW; ++j) {
+#pragma unroll
+                for (int u = 0; u < FPI; ++u) {
+                    const float x = j < k ? win[(f + u) * stride + j] : 0.f;  // f + u < C0_FRAMES: inside the staged window
+                    const f32x2 xx = {x, x};
+#pragma unroll
+                    for (int i = 0; i < CP; ++i) acc[u][i] = w2[i][j] * xx + acc[u][i];
+                }
+            }
+            // channels beyond C carry zero weights and bias, so they add nothing to the sums (c0 + CPL <= C or lane idle)
+            float mu[FPI], rs[FPI];
+#pragma unroll
+            for (int u = 0; u < FPI; ++u) {
+                f32x2 s2 = acc[u][0];
+#pragma unroll
+                for (int i = 1; i < CP; ++i) s2 += acc[u][i];
+                mu[u] = wave_sum(active ? s2[0] + s2[1] : 0.f) * invC;
+            }
+#pragma unroll
+            for (int u = 0; u < FPI; ++u) {
+                const f32x2 m2 = {mu[u], mu[u]};
+                f32x2 q2 = {0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < CP; ++i) {
+                    const f32x2 d = acc[u][i] - m2;
+                    q2 = d * d + q2;
+                }
+                rs[u] = 1.0f / sqrtf(wave_sum(active ? q2[0] + q2[1] : 0.f) * invC + eps);
+            }
+#pragma unroll
+            for (int u = 0; u < FPI; ++u) {
+                const int t = f0 + f + u;
+                V2 hi[CP], lo[CP];
+                const f32x2 r2 = {rs[u], rs[u]}, m2 = {mu[u], mu[u]};
+#pragma unroll
+                for (int i = 0; i < CP; ++i) {
+                    const f32x2 v = (acc[u][i] - m2) * r2 * g2[i] + be2[i];
+                    f32x2 y = {gelu_fast(v[0]), gelu_fast(v[1])};
+                    // one register pair for y: its 16-bit image and the residual are taken from the same value (see split16)
+                    asm volatile("" : "+v"(y));
+                    hi[i] = __builtin_convertvector(y, V2);
+                    if (NT > 1) {
+                        asm volatile("" : "+v"(hi[i]));
+                        const f32x2 back = {(float)hi[i][0], (float)hi[i][1]};
+                        lo[i] = __builtin_convertvector(y - back, V2);
+                    }
+                }
+                if (active && t < T1) {
+                    T* dst = out + ((int64_t)n * T1 + t) * C + c0;
+                    if constexpr (CPL == 8) {
+                        union { V2 h[4]; typename Vec8<T>::type v; } hv, lv;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { hv.h[i] = hi[i]; if (NT > 1) lv.h[i] = lo[i]; }
+                        *(typename Vec8<T>::type*)dst = hv.v;
+                        if (NT > 1) *(typename Vec8<T>::type*)(dst + out_plane) = lv.v;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < CP; ++i) {
+                            *(V2*)(dst + 2 * i) = hi[i];
+                            if (NT > 1) *(V2*)(dst + out_plane + 2 * i) = lo[i];
+                        }
+                    }
+                }
+            }
+        }
+        return;
+    }
     for (int f = wave * FPI; f < C0_FRAMES; f += 4 * FPI) {
         float acc[FPI][CPL];
 #pragma unroll
@@ -157,21 +265,12 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ au
             }
             if (active && t < T1) {
                 T* dst = out + ((int64_t)n * T1 + t) * C + c0;
-                if constexpr (CPL == 8) {
-                    typedef typename Vec8<T>::type V8;
-                    V8 hv, lv;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) { hv[i] = hi[i]; lv[i] = NT > 1 ? lo[i] : (T)0.f; }
-                    *(V8*)dst = hv;
-                    if (NT > 1) *(V8*)(dst + out_plane) = lv;
-                } else {
-#pragma unroll
-                    for (int i = 0; i < CPL; ++i)
-                        if (c0 + i < C) {
-                            dst[i] = hi[i];
-                            if (NT > 1) dst[out_plane + i] = lo[i];
-                        }
-                }
+                for (int i = 0; i < CPL; ++i)
+                    if (c0 + i < C) {
+                        dst[i] = hi[i];
+                        if (NT > 1) dst[out_plane + i] = lo[i];
+                    }
             }
         }
     }
