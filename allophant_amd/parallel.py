@@ -9,7 +9,7 @@ single-device (no DDP / NCCL anywhere upstream) -- this module is new functional
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Tuple
+from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -93,6 +93,22 @@ def gather_predictions(local: Optional[Predictions], names_and_classes: List[Tup
             ordered[name] = tensor
         outputs = ordered
     return Predictions(outputs, all_lengths.cpu())
+
+
+def data_parallel_predict(predict: Callable[[Batch], Predictions], batch: Batch, outputs: List[Tuple[str, int]],
+                          device: torch.device, dst: int = 0, group=None,
+                          aliases: Optional[Dict[str, str]] = None) -> Optional[Predictions]:
+    """One data-parallel ``predict`` over the ranks of ``group``: every rank takes its contiguous block of utterances
+    (``shard_batch``), runs ``predict`` on it (e.g. ``lambda b: estimator.predict(b.to(device), tfi)``) and the
+    log-probabilities are gathered to ``dst`` (``gather_predictions``), which gets the ``Predictions`` of the whole batch;
+    the other ranks get ``None``.  ``outputs`` lists the distinct outputs as (name, classes) in output order and
+    ``aliases`` the names that share storage with one of them (see ``unique_outputs``): a rank whose block is empty has no
+    local prediction to read them from."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    local_batch = shard_batch(batch, rank, world)
+    local = predict(local_batch) if local_batch is not None else None
+    return gather_predictions(local, outputs, len(batch), device, dst=dst, group=group, aliases=aliases)
 
 
 class PendingGather:

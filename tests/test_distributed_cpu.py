@@ -10,7 +10,8 @@ import torch.multiprocessing as mp
 
 from allophant_amd import spec as S, synthetic
 from allophant_amd.estimator import Batch, Predictions
-from allophant_amd.parallel import gather_flat_predictions, gather_predictions, shard_batch, shard_bounds, unique_outputs
+from allophant_amd.parallel import (data_parallel_predict, gather_flat_predictions, gather_predictions, shard_batch,
+                                    shard_bounds, unique_outputs)
 
 
 def _free_port():
@@ -43,10 +44,9 @@ def _worker(rank, world, port, result_path):
     torch.set_num_threads(2)
     spec, state, audio, lengths, tfi = _setup()
     full = Batch(audio, lengths, torch.zeros(len(lengths), dtype=torch.long))
-    local_batch = shard_batch(full, rank, world)
-    local = _predict(spec, state, local_batch, tfi) if local_batch is not None else None
     names = [(n, c) for n, c in [("syllabic", 4), ("long", 4), ("phoneme", 7)]]
-    gathered = gather_predictions(local, names, len(full), torch.device("cpu"), dst=0, aliases={"phone": "phoneme"})
+    gathered = data_parallel_predict(lambda b: _predict(spec, state, b, tfi), full, names, torch.device("cpu"), dst=0,
+                                     aliases={"phone": "phoneme"})
     if rank == 0:
         torch.save({"outputs": gathered.outputs, "lengths": gathered.lengths}, result_path)
     else:
