@@ -492,3 +492,34 @@ def test_outputs_are_bitwise_reproducible(amd, utterances, seconds):
     assert torch.equal(other.predict(batch, tfi)._flat, first._flat)
     other.close()
     est.close()
+
+
+@pytest.mark.parametrize("config", ["4: hierarchical 64 x 5 s, 48 phones", "5: long-form 8 x 60 s, 200 phones"])
+def test_other_baseline_configs_full_size_properties(amd, config):
+    """BASELINE configs 4 and 5 at full size through size-independent properties (the CPU oracle would take minutes):
+    finite and normalised probabilities on every valid frame, integer frame lengths, and one utterance of the batch
+    reproduced by a solo run (no batch row leaks into another, padding included)."""
+    enc = S.xlsr_300m_encoder()
+    if config.startswith("4"):
+        spec, n, seconds, phones = S.hierarchical_spec(enc, allophone_layer=True), 64, 5.0, 48
+    else:
+        spec, n, seconds, phones = S.multitask_spec(enc, allophone_layer=True), 8, 60.0, 200
+    spec["shared_phones"] = 80
+    state = synthetic.make_state_dict(spec, seed=0)
+    est = amd.Estimator(spec, state, "cuda:0", "f16x3")
+    tfi = synthetic.make_inventory(spec, phones, seed=0)
+    audio, lengths = synthetic.make_audio(n, int(seconds * 16000), seed=99, ragged=True)
+    pred = est.predict(amd.Batch(audio.cuda(), lengths, torch.zeros(n, dtype=torch.long)), tfi)
+    assert pred.lengths.tolist() == S.frame_lengths(lengths.tolist(), spec)
+    T = pred.outputs["phoneme"].shape[0]
+    assert pred.outputs["phoneme"].shape == (T, n, phones + 1) and len(pred.outputs) == 38
+    valid = (torch.arange(T).unsqueeze(1) < pred.lengths.unsqueeze(0)).cuda()
+    for k, out in pred.outputs.items():
+        assert torch.isfinite(out[valid]).all(), k
+        assert (out.exp().sum(-1)[valid] - 1).abs().max().item() < 1e-4, k
+    i = n // 2
+    ni, ti = int(lengths[i]), int(pred.lengths[i])
+    solo = est.predict(amd.Batch(audio[i:i + 1, :ni].contiguous().cuda(), lengths[i:i + 1], torch.zeros(1, dtype=torch.long)), tfi)
+    for k in pred.outputs:
+        assert (pred.outputs[k][:ti, i] - solo.outputs[k][:ti, 0]).abs().max().item() < 2e-4, k
+    est.close()
