@@ -114,20 +114,33 @@ def padding_efficiency(batches: Iterable[Sequence[int]], frame_lengths: Sequence
 
 class PinnedCollator:
     """``collate`` into a small ring of reusable pinned host buffers (``hipHostMalloc`` per batch costs milliseconds).  A
-    buffer is reused ``depth`` batches later, i.e. after its host-to-device copy has long been consumed."""
+    slot is refilled ``depth`` batches later; the asynchronous host-to-device copy that read it may not have run yet (the
+    host runs ahead of the GPU), so whoever issues that copy hands the slot an event recorded behind it
+    (``mark_in_flight``; ``Prefetcher`` does) and the refill waits for that event first."""
 
     def __init__(self, max_samples: int, depth: int = 3):
         self._buffers = [torch.empty(max_samples, dtype=torch.float32).pin_memory() for _ in range(depth)]
+        self._events: List[Optional["torch.cuda.Event"]] = [None] * depth
         self._next = 0
+
+    def mark_in_flight(self, batch: Batch, event: "torch.cuda.Event") -> None:
+        """``event`` completes once the device copy of ``batch`` (a batch this collator returned) has read its slot."""
+        slot = getattr(batch, "_pinned_slot", None)
+        if slot is not None and slot[0] is self:
+            self._events[slot[1]] = event
 
     def __call__(self, audio: Sequence[Tensor], language_ids: Optional[Sequence[int]] = None) -> Batch:
         lengths = torch.tensor([int(a.numel()) for a in audio], dtype=torch.int64)
         longest = int(lengths.max())
         n = len(audio)
-        buf = self._buffers[self._next]
+        slot = self._next
+        buf = self._buffers[slot]
         self._next = (self._next + 1) % len(self._buffers)
         if n * longest > buf.numel():
             return collate(audio, language_ids, pin=True)  # over-long single utterance: one-off buffer
+        if self._events[slot] is not None:
+            self._events[slot].synchronize()  # the copy out of this slot has finished
+            self._events[slot] = None
         features = buf[: n * longest].view(n, longest)
         for i, a in enumerate(audio):
             k = a.numel()
@@ -135,7 +148,9 @@ class PinnedCollator:
             if k < longest:
                 features[i, k:].zero_()
         ids = torch.tensor(list(language_ids) if language_ids is not None else [0] * n, dtype=torch.int64)
-        return Batch(features, lengths, ids)
+        batch = Batch(features, lengths, ids)
+        batch._pinned_slot = (self, slot)
+        return batch
 
 
 class Prefetcher:
@@ -143,13 +158,19 @@ class Prefetcher:
     on a side stream; because ``Estimator.predict`` only *launches* work, the caller's call for batch k+1 arrives while the
     GPU is still computing batch k, so the host-side collation and the host-to-device copy of k+1 overlap the compute of k
     (the compute stream waits for the copy only when it actually consumes the batch).  ``batches`` yields CPU ``Batch``
-    objects, or anything ``fetch`` turns into one (e.g. index lists)."""
+    objects, or anything ``fetch`` turns into one (e.g. index lists).  ``collator``: the ``PinnedCollator`` the batches come
+    from, if any -- it is told when the copy out of a slot completes (event per slot)."""
 
-    def __init__(self, batches: Iterable, device: torch.device, fetch=None):
+    def __init__(self, batches: Iterable, device: torch.device, fetch=None, collator: Optional[PinnedCollator] = None):
         self._source = iter(batches)
         self._device = torch.device(device)
         self._fetch = fetch
+        self._collator = collator
         self._stream = torch.cuda.Stream(self._device)
+
+    @property
+    def copy_stream(self) -> "torch.cuda.Stream":
+        return self._stream
 
     def __iter__(self):
         return self
@@ -160,7 +181,69 @@ class Prefetcher:
         audio = batch.audio_features if batch.audio_features.is_pinned() else batch.audio_features.pin_memory()
         with torch.cuda.stream(self._stream):
             dev = audio.to(self._device, non_blocking=True)
+            slot = getattr(batch, "_pinned_slot", None)
+            if slot is not None:
+                event = torch.cuda.Event()
+                event.record(self._stream)
+                slot[0].mark_in_flight(batch, event)
         current = torch.cuda.current_stream(self._device)
         current.wait_stream(self._stream)  # stream-ordered: later launches on the compute stream see the copied batch
         dev.record_stream(current)
         return Batch(dev, batch.lengths, batch.language_ids)
+
+
+class Batcher:
+    """``Batcher`` with the reference's constructor and ``batches()`` signature (allophant/batching.py:229-342) for the
+    prediction path: ``batching_mode`` ``"utterances"`` (at most ``batch_size`` utterances per batch) or ``"frames"`` (at
+    most ``batch_size`` padded samples per batch, needs ``data_lengths``), sequential or seeded-shuffled sampler order,
+    ``skip_batches``.  ``data`` is any indexable of 1-D waveforms (or of ``(waveform, language_id)`` pairs); batches are
+    collated like upstream's ``_build_batch`` (zero right-padding).  Language oversampling is a training-side feature
+    (batching.py:32-91) and not part of this path; ``data_workers`` is accepted for signature compatibility -- collation
+    is a memcpy here, decoding audio files is the caller's job."""
+
+    def __init__(self, batch_size: int, batching_mode: str = "utterances", language_oversampling_factor: Optional[float] = None,
+                 data_workers: Optional[int] = 0, collate_fn=None):
+        mode = getattr(batching_mode, "value", batching_mode)
+        if mode not in ("utterances", "frames"):
+            raise ValueError(f"unknown batching mode {batching_mode!r}")
+        if language_oversampling_factor is not None:
+            raise NotImplementedError("language oversampling is a training-time sampler (batching.py:32-91), out of scope")
+        self._batch_size = int(batch_size)
+        self._mode = mode
+        self._collate = collate_fn or collate
+
+    @property
+    def batch_size(self) -> int:
+        return self._batch_size
+
+    def index_batches(self, n: int, data_lengths: Optional[Sequence[int]] = None, shuffle: bool = False,
+                      seed: Optional[int] = None, skip_batches: int = 0, order: Optional[Sequence[int]] = None) -> Iterator[List[int]]:
+        """The index lists behind ``batches`` (``order`` overrides the sampler, e.g. ``length_sorted_order``)."""
+        if order is None:
+            if shuffle:
+                generator = torch.Generator()
+                if seed is not None:
+                    generator.manual_seed(seed)
+                order = torch.randperm(n, generator=generator).tolist()  # RandomSampler's permutation (batching.py:319)
+            else:
+                order = range(n)
+        if self._mode == "utterances":
+            it = utterance_batches(order, self._batch_size)
+        else:
+            if data_lengths is None:
+                raise ValueError("Frame Lengths for each utterance are required for using max frame batching")
+            it = max_frame_batches(order, data_lengths, self._batch_size)
+        for i, indices in enumerate(it):  # SkipBatchSampler (batching.py:142-153)
+            if i >= skip_batches:
+                yield indices
+
+    def batches(self, data, data_lengths: Optional[Sequence[int]] = None, shuffle: bool = False, seed: Optional[int] = None,
+                skip_batches: int = 0, order: Optional[Sequence[int]] = None) -> Iterator[Batch]:
+        for indices in self.index_batches(len(data), data_lengths, shuffle, seed, skip_batches, order):
+            if not indices:
+                continue  # upstream's empty first batch for an over-long first utterance collates to nothing useful
+            items = [data[i] for i in indices]
+            if items and isinstance(items[0], (tuple, list)):
+                yield self._collate([a for a, _ in items], [int(l) for _, l in items])
+            else:
+                yield self._collate(items)

@@ -90,12 +90,27 @@ def indexer_from_checkpoint(checkpoint: Dict[str, Any]):
     state = checkpoint.get("phonetic_indexer_state")
     if not state or not state.get("table_file"):
         return None, None
-    table = AttributeTable(state["table_file"])
     allophones = state.get("language_allophones")
+    inventory = list(state.get("phoneme_inventory") or [])
+    # PhoneticAttributeIndexer.from_config (phonetic_features.py:746-786): the attribute subset is every classifier name
+    # and class dependency of the projection, in order of first appearance
+    subset: Optional[List[str]] = None
+    projection = ((checkpoint.get("config") or {}).get("nn") or {}).get("projection") or {}
+    if projection.get("classes"):
+        subset = []
+        for entry in projection["classes"]:
+            for name in (entry["name"], *entry.get("dependencies", [])):
+                if not _spec.OUTPUT_PATTERN.match(name) and name not in subset:
+                    subset.append(name)
     if allophones and allophones.get("shared_phones"):
+        # an allophone-layer checkpoint: inventories restricted to the training languages, like upstream's restored indexer
+        table = AttributeTable(state["table_file"], subset, inventory, allophones)
         training = list(allophones["shared_phones"])
     else:
-        training = list(state.get("phoneme_inventory") or [])
+        # without a mapping upstream's `from_config` restores an UNRESTRICTED indexer (the match falls through to
+        # `phoneme_subset = None`, phonetic_features.py:765-775); the training phones are the recorded inventory
+        table = AttributeTable(state["table_file"], subset)
+        training = inventory
     return table, training
 
 

@@ -75,20 +75,34 @@ struct amx_handle_s {
     int composed_class = -1;
     std::vector<bool> need_hidden;
 
-    // inventory
-    int P1 = 0;  // phones + blank, 0 = not set
+    // inventories: every distinct `target_feature_indices` matrix seen gets its own composed phoneme matrix and its own
+    // device output tables, so switching between them (the per-language loop of run.py:742-753) neither recomputes nor
+    // overwrites anything a forward pass still in flight may be reading.  Models without a composition layer own one
+    // implicit entry (P1 = 0).
+    struct Inventory {
+        std::vector<int64_t> key;  // phones, features, tfi..., offsets...
+        int P1 = 0;                // phones + blank
+        void* composed_w = nullptr;
+        float* composed_f32 = nullptr;
+        int64_t* idx_dev = nullptr;
+        OutDesc *out_unique_dev = nullptr, *out_all_dev = nullptr;
+        uint64_t last_use = 0;
+    };
+    static constexpr int INV_CAP = 16;
+    std::vector<Inventory> inventories;
+    int inv = -1;  // current entry, -1 = composition model without an inventory yet
+    uint64_t inv_clock = 0;
+    int P1 = 0;    // of the current inventory
     void* composed_w = nullptr;
     float* composed_f32 = nullptr;
-    int64_t* inv_idx = nullptr;
-    int inv_cap = 0;
 
     // logits layout
     std::vector<int> col, width;  // per class
     int ld_logits = 0;
     std::vector<amx_output_desc> outputs;  // relative to N, T of the last layout computation
     std::vector<OutDesc> out_unique, out_all;
-    OutDesc *out_unique_dev = nullptr, *out_all_dev = nullptr;
-    int layout_dev_P1 = -1;  // inventory size the device tables were built for
+    OutDesc *out_unique_dev = nullptr, *out_all_dev = nullptr;  // of the current inventory
+    int layout_inv = -2;  // inventory the host-side layout was computed for
     int layout_N = -1;
     int64_t layout_T = -1;
 
@@ -232,6 +246,10 @@ int evaluation_order(const std::vector<amx_class_desc>& cls, std::vector<int>& o
 }
 
 }  // namespace
+
+static void free_inventory(amx_handle_s::Inventory& e);
+static int install_inventory(amx_handle h, std::vector<int64_t>&& key, const std::vector<int64_t>& idx, int P1, int features,
+                             hipStream_t s);
 
 // =================================================================================================================
 // creation
@@ -561,6 +579,11 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
         TRY(upload_f32(h, tm, key, t->numel, &h->emb));
     }
 #undef TRY
+    if (h->composed_class < 0) {
+        // no composition layer: one implicit inventory (fixed output widths)
+        int rc2 = install_inventory(h, std::vector<int64_t>{}, std::vector<int64_t>{}, 0, 0, 0);
+        if (rc2) return bail(rc2);
+    }
     if (hipDeviceSynchronize() != hipSuccess) { h->err = "device synchronisation failed after packing"; return bail(AMX_EHIP); }
     *out = h;
     return AMX_OK;
@@ -574,6 +597,7 @@ extern "C" int amx_destroy(amx_handle h) {
     for (void* p : h->allocs) (void)hipFree(p);
     for (auto& kv : h->ws)
         if (kv.second.p) (void)hipFree(kv.second.p);
+    for (auto& e : h->inventories) free_inventory(e);
     for (int i = 0; i < amx_handle_s::PIN_SLOTS; ++i) {
         if (h->h_lengths_pinned[i]) (void)hipHostFree(h->h_lengths_pinned[i]);
         if (h->h_frames_pinned[i]) (void)hipHostFree(h->h_frames_pinned[i]);
@@ -592,12 +616,119 @@ extern "C" int64_t amx_device_bytes(amx_handle h) { return h ? h->weight_bytes +
 // =================================================================================================================
 // inventory
 // =================================================================================================================
-extern "C" int amx_set_inventory(amx_handle h, const int64_t* tfi, int phones, int features, const int64_t* offsets) {
+// (column, width) of every class in the logits buffer and the (column, classes, class prefix) tables of the outputs for an
+// inventory of P1 - 1 phones; geometry-independent
+static void build_tables(amx_handle h, int P1, std::vector<int>& col, std::vector<int>& width, int& ld_logits,
+                         std::vector<OutDesc>& uniq, std::vector<OutDesc>& all) {
+    const int nc = (int)h->classes.size();
+    col.assign(nc, 0);
+    width.assign(nc, 0);
+    int colp = 0;
+    for (int ci : h->order) {
+        col[ci] = colp;
+        width[ci] = ci == h->composed_class ? P1 : h->classes[ci].out_features;
+        colp += width[ci];
+    }
+    ld_logits = round_up(colp, 4);
+    uniq.clear();
+    all.clear();
+    int64_t prefix = 0;
+    for (int ci : h->order) {
+        OutDesc od{col[ci], width[ci], prefix};
+        uniq.push_back(od);
+        if (!strcmp(h->classes[ci].name, "phoneme") && h->cfg.allophone_layer) all.push_back(od);  // "phone" alias
+        all.push_back(od);
+        prefix += width[ci];
+    }
+}
+
+static void free_inventory(amx_handle_s::Inventory& e) {
+    if (e.composed_w) (void)hipFree(e.composed_w);
+    if (e.composed_f32) (void)hipFree(e.composed_f32);
+    if (e.idx_dev) (void)hipFree(e.idx_dev);
+    if (e.out_unique_dev) (void)hipFree(e.out_unique_dev);
+    if (e.out_all_dev) (void)hipFree(e.out_all_dev);
+    e = amx_handle_s::Inventory{};
+}
+
+static void select_inventory(amx_handle h, int i) {
+    auto& e = h->inventories[i];
+    e.last_use = ++h->inv_clock;
+    h->inv = i;
+    h->P1 = e.P1;
+    h->composed_w = e.composed_w;
+    h->composed_f32 = e.composed_f32;
+    h->out_unique_dev = e.out_unique_dev;
+    h->out_all_dev = e.out_all_dev;
+}
+
+// builds a new cache entry on `s`: every buffer is fresh, so nothing in flight can be reading it; the uploads come from
+// pageable host memory (staged by the runtime before the call returns) and are ordered before later work on `s`
+static int install_inventory(amx_handle h, std::vector<int64_t>&& key, const std::vector<int64_t>& idx, int P1, int features,
+                             hipStream_t s) {
+    int slot = -1;
+    if ((int)h->inventories.size() < amx_handle_s::INV_CAP) {
+        h->inventories.emplace_back();
+        slot = (int)h->inventories.size() - 1;
+    } else {
+        // evict the least recently used entry; a forward pass still in flight may read its buffers
+        for (int i = 0; i < (int)h->inventories.size(); ++i)
+            if (i != h->inv && (slot < 0 || h->inventories[i].last_use < h->inventories[slot].last_use)) slot = i;
+        HIPCHK(h, hipDeviceSynchronize());
+        free_inventory(h->inventories[slot]);
+    }
+    auto& e = h->inventories[slot];
+    e.P1 = P1;
+    const int E = h->cfg.embedding_size;
+    std::vector<int> col, width;
+    int ld;
+    std::vector<OutDesc> uniq, all;
+    build_tables(h, P1, col, width, ld, uniq, all);
+    auto fail_free = [&](int code, const char* msg) {
+        free_inventory(e);
+        if (slot == (int)h->inventories.size() - 1) h->inventories.pop_back();
+        return fail(h, code, msg);
+    };
+    if (hipMalloc((void**)&e.out_unique_dev, uniq.size() * sizeof(OutDesc)) != hipSuccess ||
+        hipMalloc((void**)&e.out_all_dev, all.size() * sizeof(OutDesc)) != hipSuccess)
+        return fail_free(AMX_ENOMEM, "inventory table allocation failed");
+    if (hipMemcpyAsync(e.out_unique_dev, uniq.data(), uniq.size() * sizeof(OutDesc), hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(e.out_all_dev, all.data(), all.size() * sizeof(OutDesc), hipMemcpyHostToDevice, s) != hipSuccess)
+        return fail_free(AMX_EHIP, "inventory table upload failed");
+    if (P1 > 0) {
+        if (hipMalloc((void**)&e.idx_dev, idx.size() * 8) != hipSuccess ||
+            hipMalloc(&e.composed_w, (size_t)P1 * E * 2 * h->NT) != hipSuccess ||
+            hipMalloc((void**)&e.composed_f32, (size_t)P1 * E * 4) != hipSuccess)
+            return fail_free(AMX_ENOMEM, "inventory allocation failed");
+        if (hipMemcpyAsync(e.idx_dev, idx.data(), idx.size() * 8, hipMemcpyHostToDevice, s) != hipSuccess)
+            return fail_free(AMX_EHIP, "inventory upload failed");
+        launch_compose(h->prec, h->emb, E, e.idx_dev, P1, features, e.composed_f32, e.composed_w, (int64_t)P1 * E, E, s);
+        if (hipGetLastError() != hipSuccess) return fail_free(AMX_EHIP, "compose kernel launch failed");
+    }
+    // the staged uploads above read host vectors that die with this call: HIP stages pageable sources before returning
+    e.key = std::move(key);
+    select_inventory(h, slot);
+    return AMX_OK;
+}
+
+extern "C" int amx_set_inventory(amx_handle h, const int64_t* tfi, int phones, int features, const int64_t* offsets,
+                                 void* stream) {
     if (!h) return AMX_EINVAL;
     if (h->composed_class < 0) return fail(h, AMX_ESTATE, "model has no embedding composition layer");
     if (!tfi || !offsets || phones < 1 || features < 1) return fail(h, AMX_EINVAL, "bad inventory arguments");
     HIPCHK(h, hipSetDevice(h->device));
-    const int P1 = phones + 1, E = h->cfg.embedding_size;
+    std::vector<int64_t> key;
+    key.reserve(2 + (size_t)phones * features + features);
+    key.push_back(phones);
+    key.push_back(features);
+    key.insert(key.end(), tfi, tfi + (size_t)phones * features);
+    key.insert(key.end(), offsets, offsets + features);
+    for (int i = 0; i < (int)h->inventories.size(); ++i)
+        if (h->inventories[i].key == key) {
+            select_inventory(h, i);
+            return AMX_OK;
+        }
+    const int P1 = phones + 1;
     std::vector<int64_t> idx((size_t)P1 * features, -1);
     idx[0] = 0;  // blank embedding = row 0 (acoustic_model.py:226-228)
     for (int p = 0; p < phones; ++p)
@@ -606,27 +737,52 @@ extern "C" int amx_set_inventory(amx_handle h, const int64_t* tfi, int phones, i
             if (r < 0 || r >= h->emb_rows) return fail(h, AMX_EINVAL, "composition feature index out of range of the embedding table");
             idx[(size_t)(p + 1) * features + f] = r;
         }
-    void *idx_dev, *cw, *cf;
-    int rc;
-    if ((rc = ws_get(h, "inv_idx", idx.size() * 8, &idx_dev))) return rc;
-    if ((rc = ws_get(h, "composed_w", (size_t)P1 * E * 2 * h->NT, &cw))) return rc;
-    if ((rc = ws_get(h, "composed_f32", (size_t)P1 * E * 4, &cf))) return rc;
-    HIPCHK(h, hipMemcpy(idx_dev, idx.data(), idx.size() * 8, hipMemcpyHostToDevice));
-    launch_compose(h->prec, h->emb, E, (const int64_t*)idx_dev, P1, features, (float*)cf, cw, (int64_t)P1 * E, E, 0);
-    HIPCHK(h, hipDeviceSynchronize());
-    h->composed_w = cw;
-    h->composed_f32 = (float*)cf;
-    h->P1 = P1;
-    h->layout_N = -1;  // logits layout depends on the inventory size
-    return AMX_OK;
+    return install_inventory(h, std::move(key), idx, P1, features, (hipStream_t)stream);
 }
 
 // =================================================================================================================
 // layout
 // =================================================================================================================
+// frontend.py:192-203 applied per conv layer (acoustic_model.py:832-835) with floor division; 0 as soon as a layer's input
+// is shorter than its kernel (the reference's formula goes non-positive there)
 static int64_t frames_of(const amx_config& c, int64_t len) {
-    for (int i = 0; i < c.n_conv; ++i) len = (len - c.conv_kernel[i]) / c.conv_stride[i] + 1;  // floor for len >= kernel
+    for (int i = 0; i < c.n_conv; ++i) {
+        if (len < c.conv_kernel[i]) return 0;
+        len = (len - c.conv_kernel[i]) / c.conv_stride[i] + 1;
+    }
     return len;
+}
+
+// Largest N for which a batch padded to L samples stays inside the 32-bit offsets of the kernels: in the two-plane modes
+// the lo plane of an activation is addressed as (32-bit byte offset of the hi plane element) + (plane bytes), so every
+// activation plane plus the largest offset inside a tile must stay below 4 GiB; row indices are 32-bit.
+static int64_t max_utterances_for(const amx_config& c, int NT, int64_t L) {
+    int64_t Ts[AMX_MAX_CONV + 1];
+    Ts[0] = L;
+    for (int i = 0; i < c.n_conv; ++i) {
+        if (Ts[i] < c.conv_kernel[i]) return 0;
+        Ts[i + 1] = (Ts[i] - c.conv_kernel[i]) / c.conv_stride[i] + 1;
+    }
+    const int64_t T = Ts[c.n_conv], Tp = (T + 63) / 64 * 64;
+    const int64_t C = c.conv_dim, D = c.hidden, F = c.ffn, H = c.heads;
+    const int64_t wide = std::max<int64_t>(F, 3 * D);
+    const int64_t LIMIT = ((int64_t)1 << 32) - ((int64_t)64 << 20);  // 4 GiB minus slack for the offsets inside a tile
+    int64_t best = INT32_MAX / std::max<int64_t>(Ts[1], 1);           // 32-bit row indices of the first conv output
+    best = std::min(best, (int64_t)INT32_MAX / std::max<int64_t>(T, 1));
+    best = std::min(best, ((int64_t)INT32_MAX * 4 / wide) / std::max<int64_t>(T, 1));
+    if (NT > 1) {
+        // conv activations [N * Ts[i], C]: plane + one utterance (tiles crossing an utterance boundary)
+        for (int i = 1; i < c.n_conv; ++i) best = std::min(best, LIMIT / (Ts[i] * C * 2) - 1);
+        best = std::min(best, LIMIT / (T * wide * 2));        // FFN activation / fused QKV rows
+        best = std::min(best, LIMIT / (H * Tp * 64 * 2));     // Q / K / V planes
+        best = std::min(best, LIMIT / ((T + c.pos_kernel) * D * 2));  // padded image of the positional convolution
+    }
+    return std::max<int64_t>(best, 0);
+}
+
+extern "C" int64_t amx_max_utterances(amx_handle h, int64_t L) {
+    if (!h || L < 1) return 0;
+    return max_utterances_for(h->cfg, h->NT, L);
 }
 
 static int compute_layout(amx_handle h, int N, int64_t L) {
@@ -637,27 +793,14 @@ static int compute_layout(amx_handle h, int N, int64_t L) {
         T = (T - h->cfg.conv_kernel[i]) / h->cfg.conv_stride[i] + 1;
     }
     if (T > 1 << 20) return fail(h, AMX_EINVAL, "utterance too long");
-    if (h->composed_class >= 0 && h->P1 == 0)
+    if (h->inv < 0)
         return fail(h, AMX_ESTATE, "composition model needs amx_set_inventory before prediction (the training inventory is a non-persistent buffer upstream)");
-    if (h->layout_N == N && h->layout_T == T) return AMX_OK;
-    const int nc = (int)h->classes.size();
-    h->col.assign(nc, 0);
-    h->width.assign(nc, 0);
-    int colp = 0;
-    for (int ci : h->order) {
-        h->col[ci] = colp;
-        h->width[ci] = ci == h->composed_class ? h->P1 : h->classes[ci].out_features;
-        colp += h->width[ci];
-    }
-    h->ld_logits = round_up(colp, 4);
+    if (h->layout_N == N && h->layout_T == T && h->layout_inv == h->inv) return AMX_OK;
+    build_tables(h, h->P1, h->col, h->width, h->ld_logits, h->out_unique, h->out_all);
     h->outputs.clear();
-    h->out_unique.clear();
-    h->out_all.clear();
-    int64_t off = 0, prefix = 0;
+    int64_t off = 0;
     for (int ci : h->order) {
         const amx_class_desc& c = h->classes[ci];
-        OutDesc od{h->col[ci], h->width[ci], prefix};
-        h->out_unique.push_back(od);
         bool is_phoneme = !strcmp(c.name, "phoneme");
         if (is_phoneme && h->cfg.allophone_layer) {
             amx_output_desc d{};
@@ -665,33 +808,17 @@ static int compute_layout(amx_handle h, int N, int64_t L) {
             d.classes = h->width[ci];
             d.offset = off;
             h->outputs.push_back(d);
-            h->out_all.push_back(od);
         }
         amx_output_desc d{};
         strncpy(d.name, c.name, AMX_NAME_LEN - 1);
         d.classes = h->width[ci];
         d.offset = off;
         h->outputs.push_back(d);
-        h->out_all.push_back(od);
         off += (int64_t)T * N * h->width[ci];
-        prefix += h->width[ci];
-    }
-    // The device tables hold (column, classes, class prefix) only -- independent of (N, T) -- so they are uploaded when the
-    // inventory changes (layout_dev_P1), never on a mere geometry change: no copy races a forward pass still in flight.
-    if (!h->out_unique_dev || h->layout_dev_P1 != h->P1) {
-        void *a, *b;
-        int rc;
-        HIPCHK(h, hipDeviceSynchronize());
-        if ((rc = ws_get(h, "out_unique", h->out_unique.size() * sizeof(OutDesc), &a))) return rc;
-        if ((rc = ws_get(h, "out_all", h->out_all.size() * sizeof(OutDesc), &b))) return rc;
-        HIPCHK(h, hipMemcpy(a, h->out_unique.data(), h->out_unique.size() * sizeof(OutDesc), hipMemcpyHostToDevice));
-        HIPCHK(h, hipMemcpy(b, h->out_all.data(), h->out_all.size() * sizeof(OutDesc), hipMemcpyHostToDevice));
-        h->out_unique_dev = (OutDesc*)a;
-        h->out_all_dev = (OutDesc*)b;
-        h->layout_dev_P1 = h->P1;
     }
     h->layout_N = N;
     h->layout_T = T;
+    h->layout_inv = h->inv;
     return AMX_OK;
 }
 
@@ -737,8 +864,12 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     for (int i = 0; i < c.n_conv; ++i) Ts[i + 1] = (Ts[i] - c.conv_kernel[i]) / c.conv_stride[i] + 1;
     const int T = (int)Ts[c.n_conv];
     const int64_t M = (int64_t)N * T;
-    if (M * std::max(F, 3 * D) > (int64_t)INT32_MAX * 4 || (int64_t)N * Ts[1] > INT32_MAX)
-        return fail(h, AMX_EINVAL, "batch too large for 32-bit row indices");
+    {
+        const int64_t nmax = max_utterances_for(c, NT, L);
+        if (N > nmax)
+            return fail(h, AMX_EINVAL, "batch too large for the 32-bit offsets of the kernels: at most " + std::to_string(nmax) +
+                                           " utterances of " + std::to_string(L) + " samples per call (amx_max_utterances); split the batch");
+    }
     const int Tp = round_up(T, 64);
 
     int64_t maxlen = 0;
@@ -746,7 +877,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         if (lengths[n] < 1 || lengths[n] > L) return fail(h, AMX_EINVAL, "lengths must lie in [1, L]");
         maxlen = std::max(maxlen, lengths[n]);
     }
-    if (maxlen != L)
+    if (maxlen != L && !(flags & AMX_FLAG_PADDED))
         return fail(h, AMX_EINVAL, "the batch must be padded to exactly max(lengths) (reference utils.py:62-63, acoustic_model.py:765-767)");
 
     // ---- pinned host staging of lengths (ring of event-guarded slots: no stream synchronisation on the hot path) ----
@@ -769,7 +900,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     for (int n = 0; n < N; ++n) {
         pin_len[n] = lengths[n];
         int64_t f = frames_of(c, lengths[n]);
-        if (lengths[n] < c.conv_kernel[0] || f < 1) return fail(h, AMX_EINVAL, "utterance shorter than the receptive field");
+        if (f < 1) return fail(h, AMX_EINVAL, "utterance shorter than the receptive field of the feature extractor");
         pin_frames[n] = (int)f;
         if (out_lengths) out_lengths[n] = f;
     }
@@ -881,13 +1012,13 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             }
         }
         g.out_f32 = (float*)preln; g.ldo = C;
-        { Timed t_(h, gemm_class(prec, g)); run_gemm(prec, g, s); }
+        { Timed t_(h, last ? AMX_KC_CONV_TAIL : gemm_class(prec, g)); run_gemm(prec, g, s); }
         if (!last) {
             { Timed t_(h, AMX_KC_ROWNORM); launch_rownorm(prec, (const float*)preln, C, rows_out, C, h->conv_g[i], h->conv_be[i], 1, nullptr, nullptr, 1e-5f,
                            0.f, other, out_plane, C, nullptr, 0, s); }
         } else if (!keep) {
             // last conv layer: LN + GELU, then the feature-projection LayerNorm in the same pass
-            { Timed t_(h, AMX_KC_ROWNORM); launch_rownorm(prec, (const float*)preln, C, rows_out, C, h->conv_g[i], h->conv_be[i], 1, h->fp_g, h->fp_b, 1e-5f,
+            { Timed t_(h, AMX_KC_CONV_TAIL); launch_rownorm(prec, (const float*)preln, C, rows_out, C, h->conv_g[i], h->conv_be[i], 1, h->fp_g, h->fp_b, 1e-5f,
                            c.eps, other, out_plane, C, nullptr, 0, s); }
         } else {
             { Timed t_(h, AMX_KC_ROWNORM); launch_rownorm(prec, (const float*)preln, C, rows_out, C, h->conv_g[i], h->conv_be[i], 1, nullptr, nullptr, 1e-5f,
@@ -1119,6 +1250,19 @@ extern "C" int amx_greedy_ctc(amx_handle h, const float* out, const int64_t* fra
     HIPCHK(h, hipStreamSynchronize(s));  // fl is pageable host memory
     launch_greedy_ctc(h->out_all_dev, (int)h->out_all.size(), out, (const int*)d_fl, N, T, tokens, timesteps, counts, scores, s);
     HIPCHK(h, hipGetLastError());
+    return AMX_OK;
+}
+
+extern "C" int amx_greedy_ctc_emissions(int device, const float* emissions, int64_t stride_n, int64_t stride_t,
+                                        const int32_t* frame_lengths, int N, int64_t T, int C, int blank_index,
+                                        int64_t* tokens, int64_t* timesteps, int32_t* counts, float* scores, void* stream) {
+    if (!emissions || !frame_lengths || !tokens || !timesteps || !counts || !scores) return fail(nullptr, AMX_EINVAL, "null buffer");
+    if (N < 1 || T < 1 || C < 1) return fail(nullptr, AMX_EINVAL, "empty emission tensor");
+    if ((size_t)T * 4 + 2048 > 64 * 1024) return fail(nullptr, AMX_EINVAL, "utterance too long for the on-device greedy decoder");
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, AMX_EHIP, "hipSetDevice failed");
+    launch_greedy_ctc_emissions(emissions, stride_n, stride_t, frame_lengths, N, (int)T, C, blank_index, tokens, timesteps, counts,
+                                scores, (hipStream_t)stream);
+    if (hipGetLastError() != hipSuccess) return fail(nullptr, AMX_EHIP, "greedy CTC kernel launch failed");
     return AMX_OK;
 }
 

@@ -265,11 +265,9 @@ __global__ __launch_bounds__(WAVES * 64, AMX_ATTN_OCC) void attn_kernel(const At
 template <typename T, int NT, int WAVES>
 void launch_attn(const AttnParams& p, hipStream_t stream) {
     constexpr int lds = 2 * NT * 2 * TILE;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static OncePerDevice attr;
+    if (attr.first())
         (void)hipFuncSetAttribute((const void*)attn_kernel<T, NT, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
     const int qblocks = (p.T + WAVES * 32 - 1) / (WAVES * 32);
     dim3 grid((unsigned)(8 * ((p.N * p.H + 7) / 8) * qblocks));
     hipLaunchKernelGGL((attn_kernel<T, NT, WAVES>), grid, dim3(WAVES * 64), lds, stream, p);

@@ -101,6 +101,25 @@ __device__ __forceinline__ float wave_max(float v) {
     return fmaxf(fmaxf(lane_value(v, 0), lane_value(v, 16)), fmaxf(lane_value(v, 32), lane_value(v, 48)));
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) and the CU count are properties of a device, not of the process: a
+// process may hold handles on several GPUs, so "done once" flags are kept per device id.
+constexpr int MAX_DEVICES = 64;
+inline int current_device() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MAX_DEVICES) d = 0;
+    return d;
+}
+struct OncePerDevice {
+    bool done[MAX_DEVICES] = {};
+    // true exactly once per device (the caller then sets the attribute)
+    bool first() {
+        const int d = current_device();
+        if (done[d]) return false;
+        done[d] = true;
+        return true;
+    }
+};
+
 // ---------------------------------------------------------------------------------------------------------------
 // GEMM:  C[M,N] = epilogue( A[M,K] . W[N,K]^T )      A and W are K-contiguous 16-bit planes
 // ---------------------------------------------------------------------------------------------------------------
@@ -222,6 +241,9 @@ void launch_logsoftmax_out(const OutDesc* descs_dev, int n_out, const float* log
                            int log_probs, float* out, hipStream_t s);
 void launch_greedy_ctc(const OutDesc* descs_dev, int n_out, const float* out, const int* frame_len, int N, int T,
                        int64_t* tokens, int64_t* timesteps, int* counts, float* scores, hipStream_t s);
+// the same decoder over one [N, T, C] emission tensor with element strides (stride_n, stride_t, 1)
+void launch_greedy_ctc_emissions(const float* emissions, int64_t stride_n, int64_t stride_t, const int* frame_len, int N, int T,
+                                 int C, int blank, int64_t* tokens, int64_t* timesteps, int* counts, float* scores, hipStream_t s);
 
 // weight packing helpers (device side; run once at amx_create / amx_set_inventory)
 void launch_pack_matrix(int prec, const float* src, int rows, int cols, int64_t src_row_stride, int64_t src_col_stride,

@@ -27,6 +27,20 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------------
 // host side: eligibility, the plan (tile height / K chunks / kernel) of a product, launches
 // ---------------------------------------------------------------------------------------------------------------
+int device_cus() {
+    static int per_device[MAX_DEVICES] = {};
+    const int dev = current_device();
+    int& cus = per_device[dev];
+    if (!cus) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+        cus -= cus % 8;  // the tile order assumes sequence numbers i and i + grid share an XCD
+        if (cus < 8) cus = 8;
+    }
+    return cus;
+}
+
 bool ln_eligible(int NT, const GemmParams& p) {
     if (g_force_generic_gemm) return false;
     if (!p.ln_gamma || !p.ln_beta || p.act != 1 || !p.out_p || p.out_f32 || p.residual || p.row_len || p.mode != 0) return false;
@@ -47,20 +61,11 @@ bool ln_eligible(int NT, const GemmParams& p) {
 
 template <typename T, int NT>
 void launch_gemm_ln(const GemmParams& p, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static OncePerDevice attr;
+    if (attr.first())
         (void)hipFuncSetAttribute((const void*)gemm_ln_kernel<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, ppw::LDS_BYTES);
-        attr_set = true;
-    }
     const int tiles = (p.M + ppw::BM - 1) / ppw::BM;
-    int cus = 256;
-    {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        static int cached = 0;
-        if (!cached && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cached = prop.multiProcessorCount;
-        if (cached > 0) cus = cached;
-    }
+    const int cus = device_cus();
     dim3 grid(tiles < cus ? tiles : cus, 1, 1);
     hipLaunchKernelGGL((gemm_ln_kernel<T, NT>), grid, dim3(512), ppw::LDS_BYTES, stream, p);
 }
@@ -93,19 +98,6 @@ bool pp_eligible(int NT, const GemmParams& p) {
         return false;
     }
     return true;
-}
-
-int device_cus() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-        cus -= cus % 8;  // the tile order assumes sequence numbers i and i + grid share an XCD
-        if (cus < 8) cus = 8;
-    }
-    return cus;
 }
 
 // Number of K chunks for a product of `tiles` output tiles: 1 when no workspace was given or the tiles alone occupy more
@@ -154,11 +146,9 @@ void launch_fixup(const GemmParams& p, int splits, hipStream_t stream) {
 
 template <typename T, int NT, int MI>
 void launch_pp_tiles(const GemmParams& p, int splits, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static OncePerDevice attr;
+    if (attr.first())
         (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<T, NT, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, pp::LDS_BYTES);
-        attr_set = true;
-    }
     const int tiles = ((p.N + pp::BN - 1) / pp::BN) * ((p.M + MI * 32 - 1) / (MI * 32));
     const int cus = device_cus();
     const int units = tiles * splits;
@@ -239,12 +229,10 @@ int dma_tile_shape(int NT, const GemmParams& p, int zdim) {
 template <typename T, int NT, int BM, int BN, int WM, int WN, int STAGES>
 void launch_gemm_dma(const GemmParams& q, int zdim, hipStream_t stream) {
     constexpr int lds = STAGES * NT * (BM + BN) * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static OncePerDevice attr;
+    if (attr.first())
         (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<T, NT, BM, BN, WM, WN, STAGES>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
     dim3 grid((q.N + BN - 1) / BN, (q.M + BM - 1) / BM, zdim);
     hipLaunchKernelGGL((gemm_dma_kernel<T, NT, BM, BN, WM, WN, STAGES>), grid, dim3(256), lds, stream, q);
 }
@@ -255,12 +243,24 @@ void launch_gemm_dma_shape(int shape, const GemmParams& q, int zdim, hipStream_t
     else launch_gemm_dma<T, NT, 128, 64, 4, 1, 3>(q, zdim, stream);
 }
 
+// A product that fits one round of LDS-DMA tiles runs there instead of on the ping-pong kernel when it is short (below
+// ~768 rows: tools/geometry_sweep.py, 1 x 10 s 5.5 -> 4.0 ms) or when its 128 x 256 ping-pong tiles would occupy less than
+// half of the CUs (N = 1024 products of a few thousand rows: 64 tiles on 256 CUs) while 128 x 64 tiles fill them.
+// AMX_DMA_MAX_ROWS (developer switch) overrides the row threshold of the second rule.
+int dma_preferred_shape(int NT, const GemmParams& p) {
+    static const int max_rows = getenv("AMX_DMA_MAX_ROWS") ? atoi(getenv("AMX_DMA_MAX_ROWS")) : 4096;
+    const int shape = dma_tile_shape(NT, p, 1);
+    if (!shape) return 0;
+    if (p.M < 768) return shape;
+    const int pp_tiles = ((p.N + pp::BN - 1) / pp::BN) * ((p.M + 127) / 128);
+    if (p.M < max_rows && pp_tiles * 2 <= device_cus()) return shape;
+    return 0;
+}
+
 template <typename T, int NT>
 void launch_gemm_t(const GemmParams& p, hipStream_t stream) {
-    // below ~768 rows a product that fits one round of LDS-DMA tiles is faster there than on 128-row ping-pong tiles
-    // (tools/geometry_sweep.py: 1 x 10 s 5.5 -> 4.0 ms); everything else the ping-pong kernel accepts goes to it
-    const int shape = dma_tile_shape(NT, p, 1);
-    if (!(shape && p.M < 768) && launch_gemm_pp<T, NT>(p, stream)) return;
+    if (!dma_preferred_shape(NT, p) && launch_gemm_pp<T, NT>(p, stream)) return;
+    const int shape = dma_tile_shape(NT, p, 1);  // preferred, or the ping-pong kernel rejected the product
     if (shape) {
         // the ring hides the memory latency, so the K loop is only cut where it is long (K = 4096) and the grid small
         const int bm = shape == 2 ? 64 : 128, bn = shape == 2 ? 32 : 64;
@@ -326,7 +326,7 @@ bool gemm_fuses_ln(int prec, const GemmParams& p_in) { return ln_eligible(prec_p
 bool gemm_uses_pp(int prec, const GemmParams& p_in) {
     const GemmParams p = with_vec_flag(p_in);
     const int NT = prec_planes(prec);
-    return pp_eligible(NT, p) && !(p.M < 768 && dma_tile_shape(NT, p, 1));  // the routing of launch_gemm_t
+    return pp_eligible(NT, p) && !dma_preferred_shape(NT, p);  // the routing of launch_gemm_t
 }
 
 void launch_gemm(int prec, const GemmParams& p_in, hipStream_t stream) {

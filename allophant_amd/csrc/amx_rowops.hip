@@ -569,24 +569,19 @@ __global__ __launch_bounds__(256) void logsoftmax_out_kernel(const OutDesc* __re
 // greedy CTC (reference predictions.py:194-207): argmax, collapse repeats, drop blank 0, 1-based start timesteps,
 // score = sum of the per-frame maxima.  One block per (output, utterance).
 // ----------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void greedy_ctc_kernel(const OutDesc* __restrict__ descs, const float* __restrict__ out,
-                                                         const int* __restrict__ frame_len, int N, int T,
-                                                         int64_t* __restrict__ tokens, int64_t* __restrict__ timesteps,
-                                                         int* __restrict__ counts, float* __restrict__ scores) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// one workgroup decodes one utterance of one output: frame t of the utterance is the C floats at base + t * stride_t
+__device__ __forceinline__ void greedy_ctc_block(const float* __restrict__ base, int64_t stride_t, int C, int len, int T,
+                                                 int blank, int64_t* __restrict__ tok, int64_t* __restrict__ ts, int* __restrict__ count,
+                                                 float* __restrict__ score_out, unsigned char* smem) {
     int* idx = (int*)smem;          // [T]
     int* scan = idx + T;            // [256]
     float* fred = (float*)(scan + 256);  // [256]
-    const int o = blockIdx.y, n = blockIdx.x;
-    const OutDesc d = descs[o];
-    const int len = frame_len[n] < T ? frame_len[n] : T;
-    const float* base = out + (int64_t)T * N * d.prefix;
     float score = 0.f;
     for (int t = threadIdx.x; t < len; t += 256) {
-        const float* p = base + ((int64_t)t * N + n) * d.C;
+        const float* p = base + (int64_t)t * stride_t;
         float best = p[0];
         int bi = 0;
-        for (int c = 1; c < d.C; ++c) {
+        for (int c = 1; c < C; ++c) {
             float v = p[c];
             if (v > best) { best = v; bi = c; }
         }
@@ -601,7 +596,7 @@ __global__ __launch_bounds__(256) void greedy_ctc_kernel(const OutDesc* __restri
     int cnt = 0;
     for (int t = lo; t < hi; ++t) {
         bool start = t == 0 || idx[t] != idx[t - 1];
-        cnt += (start && idx[t] != 0) ? 1 : 0;
+        cnt += (start && idx[t] != blank) ? 1 : 0;
     }
     scan[threadIdx.x] = cnt;
     __syncthreads();
@@ -614,18 +609,42 @@ __global__ __launch_bounds__(256) void greedy_ctc_kernel(const OutDesc* __restri
         __syncthreads();
     }
     int pos = scan[threadIdx.x] - cnt;  // exclusive prefix
-    int64_t* tok = tokens + ((int64_t)o * N + n) * T;
-    int64_t* ts = timesteps + ((int64_t)o * N + n) * T;
     for (int t = lo; t < hi; ++t) {
         bool start = t == 0 || idx[t] != idx[t - 1];
-        if (start && idx[t] != 0) {
+        if (start && idx[t] != blank) {
             tok[pos] = idx[t];
             ts[pos] = t + 1;
             ++pos;
         }
     }
-    if (threadIdx.x == 255) counts[o * N + n] = scan[255];
-    if (threadIdx.x == 0) scores[o * N + n] = fred[0];
+    if (threadIdx.x == 255) *count = scan[255];
+    if (threadIdx.x == 0) *score_out = fred[0];
+}
+
+__global__ __launch_bounds__(256) void greedy_ctc_kernel(const OutDesc* __restrict__ descs, const float* __restrict__ out,
+                                                         const int* __restrict__ frame_len, int N, int T,
+                                                         int64_t* __restrict__ tokens, int64_t* __restrict__ timesteps,
+                                                         int* __restrict__ counts, float* __restrict__ scores) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int o = blockIdx.y, n = blockIdx.x;
+    const OutDesc d = descs[o];
+    const int len = frame_len[n] < T ? frame_len[n] : T;
+    const float* base = out + (int64_t)T * N * d.prefix + (int64_t)n * d.C;
+    greedy_ctc_block(base, (int64_t)N * d.C, d.C, len, T, 0, tokens + ((int64_t)o * N + n) * T, timesteps + ((int64_t)o * N + n) * T,
+                     counts + o * N + n, scores + o * N + n, smem);
+}
+
+// the reference decoder's own signature (predictions.py:194): one [N, T, C] emission tensor with arbitrary strides
+__global__ __launch_bounds__(256) void greedy_ctc_emissions_kernel(const float* __restrict__ emissions, int64_t stride_n,
+                                                                   int64_t stride_t, const int* __restrict__ frame_len, int T,
+                                                                   int C, int blank, int64_t* __restrict__ tokens,
+                                                                   int64_t* __restrict__ timesteps, int* __restrict__ counts,
+                                                                   float* __restrict__ scores) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n = blockIdx.x;
+    const int len = frame_len[n] < T ? frame_len[n] : T;
+    greedy_ctc_block(emissions + (int64_t)n * stride_n, stride_t, C, len < 0 ? 0 : len, T, blank, tokens + (int64_t)n * T,
+                     timesteps + (int64_t)n * T, counts + n, scores + n, smem);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -835,6 +854,13 @@ void launch_greedy_ctc(const OutDesc* descs_dev, int n_out, const float* out, co
     size_t lds = (size_t)T * sizeof(int) + 256 * sizeof(int) + 256 * sizeof(float);
     hipLaunchKernelGGL(greedy_ctc_kernel, dim3(N, n_out), dim3(256), lds, s, descs_dev, out, frame_len, N, T, tokens,
                        timesteps, counts, scores);
+}
+
+void launch_greedy_ctc_emissions(const float* emissions, int64_t stride_n, int64_t stride_t, const int* frame_len, int N, int T,
+                                 int C, int blank, int64_t* tokens, int64_t* timesteps, int* counts, float* scores, hipStream_t s) {
+    size_t lds = (size_t)T * sizeof(int) + 256 * sizeof(int) + 256 * sizeof(float);
+    hipLaunchKernelGGL(greedy_ctc_emissions_kernel, dim3(N), dim3(256), lds, s, emissions, stride_n, stride_t, frame_len, T, C,
+                       blank, tokens, timesteps, counts, scores);
 }
 
 void launch_pack_matrix(int prec, const float* src, int rows, int cols, int64_t src_row_stride, int64_t src_col_stride,

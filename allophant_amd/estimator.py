@@ -68,6 +68,8 @@ class Predictions:
     # flat device buffer the outputs are views of (kept for the on-device greedy decoder); not part of the reference API
     _flat: Optional[Tensor] = dataclasses.field(default=None, repr=False, compare=False)
     _geometry: Optional[Tuple[int, int]] = dataclasses.field(default=None, repr=False, compare=False)
+    # the `target_feature_indices` the outputs were computed under (their phoneme block is that many phones wide)
+    _inventory: Optional[Tensor] = dataclasses.field(default=None, repr=False, compare=False)
 
     def __len__(self) -> int:
         return len(self.lengths)
@@ -169,6 +171,7 @@ class Estimator:
         self._handle = handle
         self._classes = [c["name"] for c in spec["classes"]]
         self._inventory: Optional[Tensor] = None
+        self._training_inventory: Optional[Tensor] = None
         cats = spec.get("composition_categories")
         self._category_offsets = None
         if spec.get("embedding_size"):
@@ -201,8 +204,21 @@ class Estimator:
         if not isinstance(checkpoint_or_path, dict):
             checkpoint_or_path = torch.load(checkpoint_or_path, map_location="cpu", weights_only=True)
         spec = spec_from_checkpoint(checkpoint_or_path)
-        indexer, _training = indexer_from_checkpoint(checkpoint_or_path)
-        return cls(spec, checkpoint_or_path["model_state"], device, precision), indexer
+        indexer, training = indexer_from_checkpoint(checkpoint_or_path)
+        estimator = cls(spec, checkpoint_or_path["model_state"], device, precision)
+        if spec.get("embedding_size") and indexer is not None and training:
+            # `predict(batch)` without target_feature_indices falls back to the training inventory upstream
+            # (`_dense_feature_table`, acoustic_model.py:214-221); it is a non-persistent buffer there, rebuilt from the
+            # indexer at construction, so it is rebuilt from the embedded table here as well
+            estimator.set_training_inventory(indexer.composition_feature_matrix(training))
+        return estimator, indexer
+
+    def set_training_inventory(self, target_feature_indices: Tensor) -> None:
+        """The inventory ``predict(batch)`` uses when called without ``target_feature_indices`` (upstream: the
+        ``_dense_feature_table`` buffer of ``EmbeddingCompositionLayer``, acoustic_model.py:214-221)."""
+        if not self._spec.get("embedding_size"):
+            raise ValueError("model has no embedding composition layer")
+        self._training_inventory = target_feature_indices.detach().to("cpu", torch.int64).contiguous()
 
     def _set_inventory(self, tfi: Tensor) -> None:
         tfi_cpu = tfi.detach().to("cpu", torch.int64).contiguous()
@@ -211,9 +227,11 @@ class Estimator:
         if tfi_cpu.dim() != 2 or tfi_cpu.shape[1] != self._category_offsets.numel():
             raise ValueError(
                 f"target_feature_indices must be [phones, {self._category_offsets.numel()}] (composition_feature_matrix)")
-        code = self._lib.amx_set_inventory(
-            self._handle, C.cast(tfi_cpu.data_ptr(), C.POINTER(C.c_int64)), tfi_cpu.shape[0], tfi_cpu.shape[1],
-            C.cast(self._category_offsets.data_ptr(), C.POINTER(C.c_int64)))
+        with torch.cuda.device(self._device):
+            stream = torch.cuda.current_stream(self._device).cuda_stream
+            code = self._lib.amx_set_inventory(
+                self._handle, C.cast(tfi_cpu.data_ptr(), C.POINTER(C.c_int64)), tfi_cpu.shape[0], tfi_cpu.shape[1],
+                C.cast(self._category_offsets.data_ptr(), C.POINTER(C.c_int64)), C.c_void_p(stream))
         _lib.check(self._lib, self._handle, code)
         self._inventory = tfi_cpu
 
@@ -222,12 +240,13 @@ class Estimator:
         """``Estimator.predict`` (reference estimator.py:1035-1046)."""
         if self._spec.get("embedding_size"):
             if target_feature_indices is None:
-                if self._inventory is None:
+                if self._training_inventory is None:
                     raise ValueError(
                         "composition models need `target_feature_indices`: the training inventory table is a "
-                        "non-persistent buffer upstream (acoustic_model.py:214-221) and is not part of a checkpoint")
-            else:
-                self._set_inventory(target_feature_indices)
+                        "non-persistent buffer upstream (acoustic_model.py:214-221); restore the estimator from a checkpoint "
+                        "that embeds its attribute table, or call set_training_inventory()")
+                target_feature_indices = self._training_inventory
+            self._set_inventory(target_feature_indices)
         audio = batch.audio_features
         if audio.dim() != 2:
             raise ValueError("audio_features must be [N, L]")
@@ -236,6 +255,8 @@ class Estimator:
         N, L = audio.shape
         if lengths.numel() != N:
             raise ValueError("lengths must have one entry per utterance")
+        if N > 0 and int(lengths.max()) != L:
+            raise ValueError("the batch must be padded to exactly max(lengths) (reference utils.py:62-63, acoustic_model.py:765-767)")
         with torch.cuda.device(self._device):
             n_out = C.c_int()
             T = C.c_int64()
@@ -253,11 +274,38 @@ class Estimator:
             if _timing:
                 flags |= _lib.FLAG_TIMING
             stream = torch.cuda.current_stream(self._device).cuda_stream
-            code = self._lib.amx_forward(
-                self._handle, C.c_void_p(audio.data_ptr()), C.cast(lengths.data_ptr(), C.POINTER(C.c_int64)), N, L,
-                C.c_void_p(flat.data_ptr()), C.cast(out_lengths.data_ptr(), C.POINTER(C.c_int64)), flags,
-                C.c_void_p(stream))
-            _lib.check(self._lib, self._handle, code)
+            n_max = int(self._lib.amx_max_utterances(self._handle, L))
+            if N <= n_max:
+                code = self._lib.amx_forward(
+                    self._handle, C.c_void_p(audio.data_ptr()), C.cast(lengths.data_ptr(), C.POINTER(C.c_int64)), N, L,
+                    C.c_void_p(flat.data_ptr()), C.cast(out_lengths.data_ptr(), C.POINTER(C.c_int64)), flags,
+                    C.c_void_p(stream))
+                _lib.check(self._lib, self._handle, code)
+            else:
+                # a plane of the batch would pass 4 GiB (32-bit plane offsets in the kernels): run it as slices of
+                # utterances padded to the same L -- no operator mixes utterances, so the results are those of one call
+                if n_max < 1:
+                    raise ValueError(f"utterances of {L} samples are too long for one forward pass")
+                blocks = {d.offset: d.classes for d in descs}
+                for lo in range(0, N, n_max):
+                    hi = min(N, lo + n_max)
+                    n = hi - lo
+                    part_total = sum(T.value * n * c for c in blocks.values())
+                    part = torch.empty(part_total, dtype=torch.float32, device=self._device)
+                    part_lengths = torch.empty(n, dtype=torch.int64)
+                    code = self._lib.amx_forward(
+                        self._handle, C.c_void_p(audio[lo:hi].data_ptr()),
+                        C.cast(lengths[lo:hi].contiguous().data_ptr(), C.POINTER(C.c_int64)), n, L,
+                        C.c_void_p(part.data_ptr()), C.cast(part_lengths.data_ptr(), C.POINTER(C.c_int64)),
+                        flags | _lib.FLAG_PADDED, C.c_void_p(stream))
+                    _lib.check(self._lib, self._handle, code)
+                    out_lengths[lo:hi] = part_lengths
+                    src = 0
+                    for offset, c in blocks.items():  # blocks in output order: offsets ascend with the part's own
+                        flat[offset: offset + T.value * N * c].view(T.value, N, c)[:, lo:hi] = \
+                            part[src: src + T.value * n * c].view(T.value, n, c)
+                        src += T.value * n * c
+                    part.record_stream(torch.cuda.current_stream(self._device))
             # keep `audio` alive until the asynchronous kernels have consumed it
             flat.record_stream(torch.cuda.current_stream(self._device))
             audio.record_stream(torch.cuda.current_stream(self._device))
@@ -266,7 +314,7 @@ class Estimator:
         for d in descs:
             c = d.classes
             outputs[d.name.decode()] = flat[d.offset: d.offset + T.value * N * c].view(T.value, N, c)
-        return Predictions(outputs, out_lengths.to(batch.lengths.device), flat, (N, L))
+        return Predictions(outputs, out_lengths.to(batch.lengths.device), flat, (N, L), self._inventory)
 
     def greedy_decode(self, predictions: Predictions) -> Dict[str, List[List[CTCHypothesis]]]:
         """On-device ``GreedyCTCDecoder`` over every output of ``predictions`` (reference predictions.py:194-207 applied
@@ -274,6 +322,10 @@ class Estimator:
         if predictions._flat is None or predictions._geometry is None:
             raise ValueError("predictions were not produced by this estimator")
         N, L = predictions._geometry
+        if predictions._inventory is not None:
+            # the block layout depends on the inventory size: decode under the inventory of THESE predictions, whatever
+            # later predict() calls selected (a cached inventory is re-selected without device work)
+            self._set_inventory(predictions._inventory)
         names = list(predictions.outputs.keys())
         T = next(iter(predictions.outputs.values())).shape[0]
         with torch.cuda.device(self._device):
@@ -354,13 +406,82 @@ class Estimator:
 
 
 class GreedyCTCDecoder:
-    """API-compatible stand-in for the reference ``GreedyCTCDecoder`` (predictions.py:189-207) bound to an estimator: call
-    it with the ``Predictions`` object to decode on the device, or use ``Estimator.greedy_decode`` directly."""
+    """``GreedyCTCDecoder`` with the reference's signature (predictions.py:189-207), decoding on the device:
 
-    def __init__(self, estimator: Estimator, blank_index: int = 0):
-        if blank_index != 0:
-            raise ValueError("the CTC blank is index 0 (config.py:555)")
-        self._estimator = estimator
+        decoder = GreedyCTCDecoder()
+        hypotheses = decoder(outputs.transpose(1, 0), model_outputs.lengths)     # run.py:767-774, README.md:120-125
 
-    def __call__(self, predictions: Predictions) -> Dict[str, List[List[CTCHypothesis]]]:
-        return self._estimator.greedy_decode(predictions)
+    ``log_emissions`` is a ``[N, T, C]`` fp32 tensor on an MI355X (any strides with a unit class stride: the transposed
+    view of a ``[T, N, C]`` output is read in place, no copy), ``lengths`` the ``[N]`` frame lengths.  Returns, per
+    utterance, ``[CTCHypothesis(tokens, [], score, timesteps)]`` like the reference.  There is no CPU path.
+
+    Also accepted, for the whole-prediction form: ``GreedyCTCDecoder(estimator)(predictions)`` decodes every output of a
+    ``Predictions`` object in one launch (``Estimator.greedy_decode``)."""
+
+    def __init__(self, blank_index_or_estimator=0, blank_index: Optional[int] = None):
+        self._estimator = None
+        if isinstance(blank_index_or_estimator, Estimator):
+            self._estimator = blank_index_or_estimator
+            self._blank_index = 0 if blank_index is None else int(blank_index)
+            if self._blank_index != 0:
+                raise ValueError("the CTC blank of model outputs is index 0 (config.py:555)")
+        else:
+            self._blank_index = int(blank_index_or_estimator)
+
+    def __call__(self, log_emissions, lengths: Optional[Tensor] = None):
+        if isinstance(log_emissions, Predictions):
+            if self._estimator is None:
+                raise ValueError("decoding a Predictions object needs GreedyCTCDecoder(estimator)")
+            return self._estimator.greedy_decode(log_emissions)
+        if lengths is None:
+            raise TypeError("__call__() missing 1 required positional argument: 'lengths'")
+        return greedy_ctc_decode(log_emissions, lengths, self._blank_index)
+
+
+def greedy_ctc_decode(log_emissions: Tensor, lengths: Tensor, blank_index: int = 0) -> List[List[CTCHypothesis]]:
+    """``GreedyCTCDecoder.__call__`` (reference predictions.py:194-207) through ``amx_greedy_ctc_emissions``."""
+    if log_emissions.dim() != 3:
+        raise ValueError("log_emissions must be [N, T, C]")
+    if log_emissions.device.type != "cuda":
+        raise RuntimeError("allophant_amd decodes on an MI355X only (log_emissions must be a cuda tensor); there is no CPU fallback")
+    lib = _lib.load()
+    device = log_emissions.device
+    if log_emissions.dtype != torch.float32:
+        log_emissions = log_emissions.float()
+    if log_emissions.stride(2) != 1:
+        log_emissions = log_emissions.contiguous()
+    N, T, Cn = log_emissions.shape
+    if not 0 <= blank_index < Cn:
+        raise ValueError("blank_index out of range")
+    if N == 0:
+        return []
+    with torch.cuda.device(device):
+        frame_lengths = lengths.detach().to(device=device, dtype=torch.int32).contiguous()
+        tokens = torch.empty(N, T, dtype=torch.int64, device=device)
+        timesteps = torch.empty_like(tokens)
+        counts = torch.empty(N, dtype=torch.int32, device=device)
+        scores = torch.empty(N, dtype=torch.float32, device=device)
+        stream = torch.cuda.current_stream(device).cuda_stream
+        index = device.index if device.index is not None else torch.cuda.current_device()
+        code = lib.amx_greedy_ctc_emissions(
+            index, C.c_void_p(log_emissions.data_ptr()), log_emissions.stride(0), log_emissions.stride(1),
+            C.c_void_p(frame_lengths.data_ptr()), N, T, Cn, blank_index, C.c_void_p(tokens.data_ptr()),
+            C.c_void_p(timesteps.data_ptr()), C.c_void_p(counts.data_ptr()), C.c_void_p(scores.data_ptr()),
+            C.c_void_p(stream))
+        _lib.check(lib, None, code)
+        counts_h, scores_h, tokens_h, timesteps_h = counts.cpu(), scores.cpu(), tokens.cpu(), timesteps.cpu()
+    result = []
+    for n in range(N):
+        k = int(counts_h[n])
+        result.append([CTCHypothesis(tokens_h[n, :k].clone(), [], float(scores_h[n]), timesteps_h[n, :k].clone())])
+    return result
+
+
+def feature_decoders(indexer, beam_width: int = 1, feature_names=None, n_best: int = 1) -> Dict[str, GreedyCTCDecoder]:
+    """``predictions.feature_decoders`` (reference predictions.py:245-254) for greedy decoding: one decoder per feature
+    name of ``indexer`` (an ``AttributeTable`` or anything with ``feature_names``).  Beam search (``beam_width > 1``) is the
+    torchaudio/flashlight CPU decoder upstream and is not part of this path."""
+    if beam_width != 1 or n_best != 1:
+        raise NotImplementedError("only greedy decoding (beam_width=1) runs on the device; beam search is out of scope")
+    names = indexer.feature_names if feature_names is None else feature_names
+    return {name: GreedyCTCDecoder() for name in names}

@@ -9,15 +9,15 @@ import ctypes as C
 import os
 from typing import Optional
 
-AMX_ABI_VERSION = 2
+AMX_ABI_VERSION = 3
 AMX_MAX_CONV = 8
 AMX_MAX_DEPS = 64
 AMX_NAME_LEN = 48
 
 AMX_OK, AMX_EINVAL, AMX_EHIP, AMX_ESTATE, AMX_ENOMEM = 0, -1, -2, -3, -4
 PRECISIONS = {"bf16": 0, "f16": 1, "bf16x3": 2, "f16x3": 3}
-FLAG_HOST_IO, FLAG_RAW_LOGITS, FLAG_KEEP_HIDDEN, FLAG_TIMING = 1, 2, 4, 8
-KERNEL_CLASSES = ["gemm_pp", "gemm_tile", "attention", "rownorm", "conv0", "other", "gemm_ln"]
+FLAG_HOST_IO, FLAG_RAW_LOGITS, FLAG_KEEP_HIDDEN, FLAG_TIMING, FLAG_PADDED = 1, 2, 4, 8, 16
+KERNEL_CLASSES = ["gemm_pp", "gemm_tile", "attention", "rownorm", "conv0", "other", "gemm_ln", "conv_tail"]
 DEP_OUTPUT = -1
 
 LIB_NAME = "liballophant_amx.so"
@@ -27,6 +27,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 EXPORTS = [
     "amx_create", "amx_destroy", "amx_last_error", "amx_set_inventory", "amx_output_layout", "amx_forward",
     "amx_synchronize", "amx_greedy_ctc", "amx_debug_fetch", "amx_device_bytes", "amx_timing_fetch",
+    "amx_max_utterances", "amx_greedy_ctc_emissions",
 ]
 
 
@@ -82,7 +83,7 @@ def load() -> C.CDLL:
     lib.amx_destroy.restype = i32
     lib.amx_last_error.argtypes = [vp]
     lib.amx_last_error.restype = C.c_char_p
-    lib.amx_set_inventory.argtypes = [vp, C.POINTER(i64), i32, i32, C.POINTER(i64)]
+    lib.amx_set_inventory.argtypes = [vp, C.POINTER(i64), i32, i32, C.POINTER(i64), vp]
     lib.amx_set_inventory.restype = i32
     lib.amx_output_layout.argtypes = [vp, i32, i64, C.POINTER(AmxOutputDesc), C.POINTER(i32), C.POINTER(i64),
                                       C.POINTER(i64)]
@@ -99,6 +100,10 @@ def load() -> C.CDLL:
     lib.amx_timing_fetch.restype = i32
     lib.amx_device_bytes.argtypes = [vp]
     lib.amx_device_bytes.restype = i64
+    lib.amx_max_utterances.argtypes = [vp, i64]
+    lib.amx_max_utterances.restype = i64
+    lib.amx_greedy_ctc_emissions.argtypes = [i32, vp, i64, i64, vp, i32, i64, i32, i32, vp, vp, vp, vp, vp]
+    lib.amx_greedy_ctc_emissions.restype = i32
     _lib = lib
     return lib
 

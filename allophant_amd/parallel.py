@@ -167,6 +167,47 @@ def gather_flat_predictions(local: Predictions, device: torch.device, dst: int =
     return pending if async_op else pending.wait()
 
 
+class DataParallelRunner:
+    """The per-step data path of data-parallel prediction as ``bench.py --gpus N`` times it (BASELINE config 3): every rank
+    predicts its shard, the log-probabilities go to rank ``dst`` in ONE flat gather per step (equal-shaped shards, e.g.
+    32 utterances over 2 / 4 / 8 ranks) or the general padded gather (ragged shards).  With ``overlap`` the gather of step k
+    stays in flight on the backend's stream under the forward pass of step k + 1 and is completed before step k + 2 is
+    enqueued; ``drain()`` completes the last one.  ``step`` returns, on ``dst``, the assembled global ``Predictions`` of the
+    most recently COMPLETED gather (the previous step when overlapping), ``None`` elsewhere / before the first completion."""
+
+    def __init__(self, predict: Callable[[Batch], Predictions], device: torch.device, dst: int = 0, group=None,
+                 overlap: bool = True, flat: bool = True, total_utterances: Optional[int] = None):
+        self._predict, self._device, self._dst, self._group = predict, device, dst, group
+        self._overlap, self._flat, self._total = overlap, flat, total_utterances
+        self._pending: Optional[PendingGather] = None
+        self.completed = 0  # gathers completed so far
+
+    def step(self, local_batch: Optional[Batch]) -> Optional[Predictions]:
+        local = self._predict(local_batch) if local_batch is not None else None
+        if not self._flat:
+            # ragged shards: synchronous padded gather (shapes differ per rank, agreed on inside)
+            unique, aliases = unique_outputs(local)
+            result = gather_predictions(local, unique, self._total, self._device, dst=self._dst, group=self._group, aliases=aliases)
+            self.completed += 1
+            return result
+        handle = gather_flat_predictions(local, self._device, dst=self._dst, group=self._group, async_op=True)
+        if not self._overlap:
+            self.completed += 1
+            return handle.wait()
+        previous, self._pending = self._pending, handle
+        if previous is None:
+            return None
+        self.completed += 1
+        return previous.wait()
+
+    def drain(self) -> Optional[Predictions]:
+        if self._pending is None:
+            return None
+        pending, self._pending = self._pending, None
+        self.completed += 1
+        return pending.wait()
+
+
 def unique_outputs(predictions: Predictions) -> Tuple[List[Tuple[str, int]], Dict[str, str]]:
     """Splits ``predictions.outputs`` into the distinct tensors (name, classes) and the aliases that share storage with
     one of them (``"phone"`` -> ``"phoneme"`` for allophone models, acoustic_model.py:161-167)."""

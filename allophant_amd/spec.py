@@ -154,6 +154,89 @@ def output_names(spec: Dict[str, Any]) -> List[str]:
     return names
 
 
+def spec_from_reference_model(model) -> Dict[str, Any]:
+    """The spec of a LIVE reference ``Allophant`` module (``estimator.model`` of kgnlp/allophant), read from the objects the
+    reference itself builds -- this is what the binding in INTEGRATION.md section 2 calls before ``amx_create``:
+
+    * encoder shape: the ``transformers.Wav2Vec2Config`` of ``model._acoustic_model._model`` (acoustic_model.py:796-826)
+      and the pre-processor's ``do_normalize`` (``_normalize``, :815);
+    * classifier graph: ``model._classes`` (configuration order, :970) with the dependencies recorded in
+      ``model._projection._ordered_nodes`` (:362-381), ``_dependency_blanks`` (:360);
+    * head shapes from the modules of ``model._projection._layers`` (``HierarchicalClassifier``, :270-306): plain
+      ``nn.Linear`` or ``ProjectingMultiheadAttention`` (time layer), composition layer, allophone layer.
+
+    Duck-typed: no reference import."""
+    acoustic = model._acoustic_model
+    config = acoustic._model.config
+    spec: Dict[str, Any] = {
+        "conv_dim": int(config.conv_dim[0]),
+        "conv_kernel": [int(k) for k in config.conv_kernel],
+        "conv_stride": [int(k) for k in config.conv_stride],
+        "hidden": int(config.hidden_size),
+        "layers": int(config.num_hidden_layers),
+        "heads": int(config.num_attention_heads),
+        "ffn": int(config.intermediate_size),
+        "pos_kernel": int(config.num_conv_pos_embeddings),
+        "pos_groups": int(config.num_conv_pos_embedding_groups),
+        "eps": float(config.layer_norm_eps),
+        "do_normalize": bool(getattr(acoustic, "_normalize", True)),
+    }
+    if any(int(d) != spec["conv_dim"] for d in config.conv_dim):
+        raise ValueError("feature-extractor layers of different widths are not supported")
+    if getattr(config, "feat_extract_norm", "layer") != "layer" or not getattr(config, "do_stable_layer_norm", True):
+        raise ValueError("only the layer-norm feature extractor / stable-layer-norm encoder variant (XLS-R) is supported")
+    projection = model._projection
+    dependencies = {name: [d.name for d in deps] for name, deps in projection._ordered_nodes}
+    embedding_size = None
+    categories = None
+    shared_phones = None
+    classes: List[Dict[str, Any]] = []
+    for name in model._classes:
+        head = projection._layers[name]
+        layer = head._time_distributed_layer
+        entry: Dict[str, Any] = {"name": name, "dependencies": dependencies[name]}
+        if hasattr(layer, "input_projection"):  # ProjectingMultiheadAttention (acoustic_model.py:237-268)
+            out_features = int(layer.input_projection.out_features)
+            entry["time_layer"] = {"num_heads": int(layer.attention.num_heads),
+                                   "positional_embeddings": layer.positional_embeddings is not None}
+        else:
+            out_features = int(layer.out_features)
+        composition = getattr(head, "_composition_layer", None)
+        allophones = getattr(head, "_allophone_layer", None)
+        if composition is not None:
+            embedding_size = out_features
+            table = composition._dense_feature_table
+            offsets = composition._category_offsets.view(-1).tolist()
+            rows = int(composition._attribute_embeddings.weight.shape[0])
+            categories = [int(b - a) for a, b in zip(offsets, offsets[1:] + [rows])]
+            entry["size"] = int(table.shape[0])
+        else:
+            entry["size"] = out_features - BLANK_OFFSET
+        if allophones is not None:
+            matrices = allophones._allophone_matrices
+            shared_phones = int(matrices.shape[1]) - BLANK_OFFSET
+            entry["size"] = int(matrices.shape[2]) - BLANK_OFFSET
+        classes.append(entry)
+    spec.update(classes=classes, dependency_blanks=bool(projection._dependency_blanks), embedding_size=embedding_size,
+                allophone_layer=bool(getattr(projection, "_uses_allophone_mapping", False)),
+                composition_categories=categories)
+    if shared_phones is not None:
+        spec["shared_phones"] = shared_phones
+    validate(spec)
+    return spec
+
+
+def training_inventory_of_reference_model(model):
+    """``_dense_feature_table - _category_offsets`` of the reference's composition layer (acoustic_model.py:191-217): the
+    inventory ``predict(batch)`` falls back to without ``target_feature_indices``, as a ``[P, F]`` int64 tensor, or
+    ``None`` for models without a composition layer."""
+    for head in model._projection._layers.values():
+        composition = getattr(head, "_composition_layer", None)
+        if composition is not None:
+            return (composition._dense_feature_table - composition._category_offsets).detach().cpu().long()
+    return None
+
+
 def validate(spec: Dict[str, Any]) -> None:
     """Mirrors the configuration errors the reference raises while building the projection (acoustic_model.py:353-466)."""
     names = [c["name"] for c in spec["classes"]]

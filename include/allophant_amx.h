@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define AMX_ABI_VERSION 2
+#define AMX_ABI_VERSION 3
 
 #define AMX_MAX_CONV 8
 #define AMX_MAX_DEPS 64
@@ -49,16 +49,19 @@ extern "C" {
 #define AMX_FLAG_RAW_LOGITS 2u   /* `log_probabilities=False` of Estimator.predict (estimator.py:1037,1040-1046) */
 #define AMX_FLAG_KEEP_HIDDEN 4u  /* keep every encoder hidden state for amx_debug_fetch */
 #define AMX_FLAG_TIMING 8u       /* bracket every kernel launch with HIP events on the launch stream (amx_timing_fetch) */
+#define AMX_FLAG_PADDED 16u      /* L may exceed max(lengths): the call is one slice of a larger batch padded to L (the
+                                    reference itself requires L == max(lengths), utils.py:62-63) */
 
 /* kernel classes reported by amx_timing_fetch */
-#define AMX_KC_GEMM_PP 0   /* gemm_pp_kernel<T, NT, MI>: ping-pong GEMM on 256x256 / 128x256 tiles -- last conv layer, feature projection, QKV/out/FFN, wide heads */
+#define AMX_KC_GEMM_PP 0   /* gemm_pp_kernel<T, NT, MI>: ping-pong GEMM on 256x256 / 128x256 tiles -- feature projection, QKV/out/FFN, wide heads */
 #define AMX_KC_GEMM_TILE 1 /* gemm_kernel<T, NT, 128, {128,64}>: grouped positional conv, narrow heads, shapes the ping-pong kernel rejects */
 #define AMX_KC_ATTENTION 2
 #define AMX_KC_ROWNORM 3
 #define AMX_KC_CONV0 4
 #define AMX_KC_OTHER 5
 #define AMX_KC_GEMM_LN 6   /* gemm_ln_kernel<T, NT>: row-complete 128x512 GEMM with fused LayerNorm + GELU -- conv layers 1-5 */
-#define AMX_KC_COUNT 7
+#define AMX_KC_CONV_TAIL 7 /* last conv layer: its GEMM (gemm_pp_kernel<T, NT, 4>) and the LayerNorm + GELU + feature-projection LayerNorm rows */
+#define AMX_KC_COUNT 8
 
 /* dependency codes in amx_class_desc.deps */
 #define AMX_DEP_OUTPUT (-1)                 /* "OUTPUT"   (allophant/config.py:636) */
@@ -130,13 +133,23 @@ const char* amx_last_error(amx_handle h); /* h may be NULL for errors of amx_cre
 /* Replaces the `target_feature_indices` argument of `Estimator.predict` / `EmbeddingCompositionLayer.forward`
  * (acoustic_model.py:219-234): `tfi` is the int64 [P, F] `composition_feature_matrix`
  * (phonetic_features.py:808-818), `category_offsets` the int64 [F] buffer `_category_offsets`
- * (acoustic_model.py:196-207, 214-217).  Host pointers.  Stays in effect until replaced. */
-int amx_set_inventory(amx_handle h, const int64_t* tfi, int phones, int features, const int64_t* category_offsets);
+ * (acoustic_model.py:196-207, 214-217).  Host pointers.  Stays in effect until replaced.  The composed phoneme matrix of a
+ * new inventory is built on `stream` (the stream of the following amx_forward calls) into buffers of its own; the library
+ * keeps the matrices of the last 16 distinct inventories, so the per-language loop of the reference (run.py:742-753: one
+ * `feature_matrix` per batch) neither recomputes them nor races a forward pass still in flight. */
+int amx_set_inventory(amx_handle h, const int64_t* tfi, int phones, int features, const int64_t* category_offsets,
+                      void* stream);
 
 /* Output geometry for a batch of N utterances padded to L samples: T = frames of the padded length,
  * `total` = floats the caller must provide to amx_forward.  `descs` may be NULL to query `n_outputs` only. */
 int amx_output_layout(amx_handle h, int N, int64_t L, amx_output_desc* descs, int* n_outputs, int64_t* T,
                       int64_t* total);
+
+/* Largest N amx_forward accepts for utterances padded to L samples: the kernels address an activation plane with 32-bit
+ * byte offsets, so in the two-plane modes every plane must stay below 4 GiB (e.g. 22 x 60 s of conv-0 output).  Larger
+ * batches are refused with AMX_EINVAL; the caller runs them as slices of at most this many utterances with
+ * AMX_FLAG_PADDED (allophant_amd/estimator.py does). */
+int64_t amx_max_utterances(amx_handle h, int64_t L);
 
 /* Replaces `Estimator.predict(batch, tfi, log_probabilities)` (estimator.py:1035-1046):
  *   audio        fp32 [N, L], zero right-padded to L == max(lengths) (batching.py:174, utils.py:62-63); device pointer
@@ -157,6 +170,16 @@ int amx_synchronize(amx_handle h, void* stream);
  * [n_outputs, N], scores fp32 [n_outputs, N] (sum of the per-frame maxima); all four are DEVICE pointers. */
 int amx_greedy_ctc(amx_handle h, const float* out, const int64_t* frame_lengths, int N, int64_t L, int64_t* tokens,
                    int64_t* timesteps, int32_t* counts, float* scores, void* stream);
+
+/* `GreedyCTCDecoder.__call__(log_emissions, lengths)` with the reference's own signature (predictions.py:194-207): one
+ * fp32 emission tensor [N, T, C] on `device` with element strides (stride_n, stride_t, 1) -- the contiguous transpose the
+ * reference's loop builds (run.py:770-773) or a strided view of a [T, N, C] output -- and int32 [N] DEVICE frame lengths.
+ * tokens / timesteps: int64 [N, T] (first counts[n] entries valid, timesteps 1-based), counts int32 [N], scores fp32 [N]
+ * (sum of the per-frame maxima over the valid frames); all DEVICE pointers.  `blank_index` is the constructor argument of
+ * the reference class (0 everywhere upstream, config.py:555).  Needs no handle, like the reference class. */
+int amx_greedy_ctc_emissions(int device, const float* emissions, int64_t stride_n, int64_t stride_t,
+                             const int32_t* frame_lengths, int N, int64_t T, int C, int blank_index, int64_t* tokens,
+                             int64_t* timesteps, int32_t* counts, float* scores, void* stream);
 
 /* Test hook: copies an intermediate of the last amx_forward to host fp32.
  *   what = 0: conv feature extractor output [N, T, conv_dim] (after the last GELU)

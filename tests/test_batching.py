@@ -54,6 +54,32 @@ def test_utterance_batches_and_sorted_order():
     assert B.padding_efficiency(sorted_, lens) > 0.9 > 0.7 > B.padding_efficiency(corpus, lens)
 
 
+def test_batcher_has_the_reference_surface():
+    """`Batcher(batch_size, batching_mode).batches(data, data_lengths, shuffle, seed, skip_batches)` (reference
+    batching.py:229-342): frames mode == the reference's MaxFrameBatchSampler batches (golden g7), utterances mode ==
+    BatchSampler(drop_last=False), SkipBatchSampler semantics, seeded shuffling, zero-padding collation."""
+    import pytest
+
+    g = _golden()
+    for case in g["sampler_cases"]:
+        if list(case["order"]) != list(range(len(case["lengths"]))):
+            continue
+        batcher = B.Batcher(case["max_frames"], "frames")
+        assert list(batcher.index_batches(len(case["lengths"]), case["lengths"])) == case["batches"]
+    data = [torch.full((n,), float(i + 1)) for i, n in enumerate((4, 9, 2, 7, 5))]
+    batches = list(B.Batcher(2).batches(data))
+    assert [b.audio_features.shape for b in batches] == [(2, 9), (2, 7), (1, 5)]
+    assert batches[0].audio_features[0].tolist() == [1.0] * 4 + [0.0] * 5 and batches[0].lengths.tolist() == [4, 9]
+    assert [len(b) for b in B.Batcher(2).batches(data, skip_batches=1)] == [2, 1]
+    with pytest.raises(ValueError, match="Frame Lengths"):
+        list(B.Batcher(100, "frames").batches(data))
+    a = list(B.Batcher(2).index_batches(5, shuffle=True, seed=7))
+    assert a == list(B.Batcher(2).index_batches(5, shuffle=True, seed=7)) and sorted(i for b in a for i in b) == list(range(5))
+    with_language = list(B.Batcher(3).batches([(d, i % 2) for i, d in enumerate(data)]))
+    assert with_language[0].language_ids.tolist() == [0, 1, 0]
+    assert B.Batcher(16, "utterances").batch_size == 16
+
+
 import pytest
 
 

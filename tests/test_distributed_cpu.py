@@ -131,3 +131,75 @@ def test_flat_gather_assembles_the_global_batch(tmp_path):
         flat = torch.randn(5 * 3 * 4 + 5 * 3 * 7, generator=g)
         assert torch.equal(got["outputs"]["syllabic"][:, 3 * rank: 3 * rank + 3], flat[: 60].view(5, 3, 4))
         assert torch.equal(got["outputs"]["phoneme"][:, 3 * rank: 3 * rank + 3], flat[60:].view(5, 3, 7))
+
+
+# ---- the N > 1 code path of bench.py (BASELINE config 3): shard_batch + DataParallelRunner (overlapped flat gather) ----
+def _flat_predictions(out, flen):
+    """The oracle's outputs in the layout ``Estimator.predict`` produces: one flat block, [T, N, C] views in output order,
+    "phone" aliasing "phoneme"."""
+    names = [k for k in out if k != "phone"]
+    flat = torch.cat([out[k].reshape(-1) for k in names])
+    views, off = {}, 0
+    for k in names:
+        t, n, c = out[k].shape
+        view = flat[off: off + t * n * c].view(t, n, c)
+        if k == "phoneme" and "phone" in out:
+            views["phone"] = view
+        views[k] = view
+        off += t * n * c
+    return Predictions(views, flen, _flat=flat)
+
+
+def _runner_worker(rank, world, port, result_path):
+    from oracle import allophant_oracle as O
+    from allophant_amd.parallel import DataParallelRunner
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    spec, state, _, _, tfi = _setup()
+    offsets = synthetic.category_offsets(spec)
+
+    def predict(batch):
+        out, flen = O.predict(batch.audio_features, batch.lengths, state, spec, tfi, offsets)
+        return _flat_predictions(out, flen)
+
+    runner = DataParallelRunner(predict, torch.device("cpu"), dst=0)
+    steps = []
+    for step in range(3):
+        # the global batch of this step (same on every rank, full-length utterances: equal shards as in the benchmark)
+        audio, lengths = synthetic.make_audio(4, 2400, seed=50 + step)
+        shard = shard_batch(Batch(audio, lengths, torch.zeros(4, dtype=torch.long)), rank, world)
+        steps.append(runner.step(shard))
+    steps.append(runner.drain())
+    assert steps[0] is None  # the first gather is still in flight when step 0 returns
+    if rank == 0:
+        assert runner.completed == 3 and all(s is not None for s in steps[1:])
+        torch.save([{"outputs": s.outputs, "lengths": s.lengths} for s in steps[1:]], result_path)
+    else:
+        assert all(s is None for s in steps)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_strong_scaling_path_two_ranks(tmp_path):
+    """bench.py --gpus N (N > 1): the global batch is sharded by ``shard_batch``, every rank predicts its shard and
+    ``DataParallelRunner`` gathers the flat log-prob blocks to rank 0, one step behind the forward passes.  With the CPU
+    oracle standing in for the HIP path, every step's gathered result must equal the single-process prediction of that
+    step's global batch."""
+    from oracle import allophant_oracle as O
+
+    world = 2
+    result_path = str(tmp_path / "runner.pt")
+    mp.spawn(_runner_worker, args=(world, _free_port(), result_path), nprocs=world, join=True)
+    got = torch.load(result_path)
+    spec, state, _, _, tfi = _setup()
+    assert len(got) == 3
+    for step, g in enumerate(got):
+        audio, lengths = synthetic.make_audio(4, 2400, seed=50 + step)
+        ref, ref_len = O.predict(audio, lengths, state, spec, tfi, synthetic.category_offsets(spec))
+        assert list(g["outputs"]) == list(ref) and g["lengths"].tolist() == ref_len.tolist()
+        for name in ref:
+            assert g["outputs"][name].shape == ref[name].shape
+            assert (g["outputs"][name] - ref[name]).abs().max().item() < 1e-4, (step, name)

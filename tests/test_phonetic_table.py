@@ -71,9 +71,13 @@ def _composition_checkpoint(golden, allophone_layer):
     if allophone_layer:
         spec["shared_phones"] = len(training)
     state = synthetic.make_state_dict(spec, seed=3)
+    phonemes = training if not allophone_layer else training[:10]
+    # LanguageAllophoneMappings dump (phonetic_features.py:40-44): per language, phoneme index -> shared-phone indices
+    mapping = {str(lang): {str(phonemes.index(p)): [training.index(p)] for p in golden["inventories"][iso] if p in phonemes}
+               for lang, iso in enumerate(["spa", "ita"])}
     indexer_state = {
-        "phoneme_inventory": training if not allophone_layer else training[:10],
-        "language_allophones": {"allophones": {}, "languages": ["es", "it"], "shared_phones": training} if allophone_layer else None,
+        "phoneme_inventory": phonemes,
+        "language_allophones": {"allophones": mapping, "languages": ["es", "it"], "shared_phones": training} if allophone_layer else None,
         "table_file": golden["table"],
     }
     return spec, state, checkpoint.make_checkpoint(spec, state, synthetic_encoder=True, indexer_state=indexer_state)
@@ -93,9 +97,10 @@ def test_checkpoint_layout_is_rebuilt_from_the_embedded_table(golden, allophone_
     assert training == golden["inventories"]["spa+ita"]
     assert table.composition_feature_matrix(training).tolist() == golden["matrices"]["spa+ita"]
     # a table that does not match the stored embedding rows is rejected
-    ckpt["phonetic_indexer_state"]["phoneme_inventory"] = ["a"]
     if ckpt["phonetic_indexer_state"]["language_allophones"]:
         ckpt["phonetic_indexer_state"]["language_allophones"]["shared_phones"] = ["a"]
+    else:
+        ckpt["phonetic_indexer_state"]["phoneme_inventory"] = ["a"]
     with pytest.raises(ValueError, match="attribute embeddings"):
         checkpoint.spec_from_checkpoint(ckpt)
 
@@ -121,3 +126,72 @@ def test_hypothesis_symbols_follow_the_reference_prediction_loop():
     assert symbols[feature] == [[[categories[0], categories[-1]]], [[categories[0]]]]
     assert table.feature_values(feature, torch.tensor([0])) == [categories[0]]
     assert hypothesis_symbols({feature: decoded[feature]}, inventory)[feature][0][0] == ["0", str(len(categories) - 1)]
+
+
+# ---- the indexer an allophone-layer checkpoint restores to (training-language restriction) ----
+G9 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g9_restricted_indexer.json")
+
+
+@pytest.fixture(scope="module")
+def restored():
+    with open(G9, encoding="utf-8") as f:
+        return json.load(f)
+
+
+def _restored_table(g9):
+    state = g9["state"]
+    return AttributeTable(state["table_file"], g9["attribute_subset"], state["phoneme_inventory"], state["language_allophones"])
+
+
+def test_restored_indexer_is_restricted_to_the_training_languages(restored):
+    """Against the REAL reference after its state() -> from_config(state_dict=...) round trip (golden g9, written by
+    oracle/gen_restricted_golden.py): inventories only for the training languages, cut to the mapping's phonemes, phonemes
+    the selected inventory lacks re-added, rows grouped by language code."""
+    table = _restored_table(restored)
+    for name, expected in restored["inventories"].items():
+        codes = name.split("+")
+        assert table.phoneme_inventory(codes if len(codes) > 1 else codes[0]) == expected, name
+    assert restored["inventories"]["deu"] == []  # in the table, not a training language
+    # the corpus inventory of Spanish lacked three table phonemes and brought two the table inventory does not list
+    spa = restored["inventories"]["spa"]
+    assert set(spa) == set(restored["corpus_inventories"]["spa"])
+    unrestricted = AttributeTable(restored["state"]["table_file"])
+    assert unrestricted.phoneme_inventory("spa") != spa and unrestricted.phoneme_inventory("deu")
+    assert table.phonemes == restored["phonemes"] and table.feature_names == restored["feature_names"]
+    assert table.shared_phones == restored["shared_phones"]
+
+
+def test_training_matrix_of_a_restored_checkpoint(restored):
+    """The matrix `predict(batch)` falls back to without target_feature_indices: `_dense_feature_table` of the reference's
+    composition layer minus its category offsets == composition_feature_matrix(shared phones)."""
+    table = _restored_table(restored)
+    training = table.composition_feature_matrix(table.shared_phones)
+    assert training.tolist() == restored["training_matrix"]
+    counts = table.category_counts(table.shared_phones)
+    offsets = [1]
+    for c in counts[:-1]:
+        offsets.append(offsets[-1] + c)
+    assert offsets == restored["category_offsets"] and 1 + sum(counts) == restored["embedding_rows"]
+
+
+def test_indexer_from_checkpoint_applies_the_restriction(restored):
+    from allophant_amd import checkpoint
+
+    ckpt = {"phonetic_indexer_state": restored["state"],
+            "config": {"nn": {"projection": {"classes": [
+                {"name": "phoneme", "dependencies": ["OUTPUT", "syllabic"]}, {"name": "syllabic", "dependencies": ["OUTPUT_3"]},
+                {"name": "long", "dependencies": ["OUTPUT"]}, {"name": "nasal", "dependencies": ["OUTPUT"]}]}}}}
+    table, training = checkpoint.indexer_from_checkpoint(ckpt)
+    assert training == restored["shared_phones"] and table.feature_names == restored["feature_names"]
+    assert table.phoneme_inventory(["spa", "ita"]) == restored["inventories"]["spa+ita"]
+    # a checkpoint without a mapping restores an unrestricted indexer (phonetic_features.py:765-775)
+    plain = dict(ckpt, phonetic_indexer_state={"phoneme_inventory": ["a", "b"], "language_allophones": None,
+                                               "table_file": restored["state"]["table_file"]})
+    table2, training2 = checkpoint.indexer_from_checkpoint(plain)
+    assert training2 == ["a", "b"] and table2.phoneme_inventory("deu")
+    # README decode loop: inventory view
+    view = table.subset(restored["inventories"]["spa"])
+    assert view.feature_values("phoneme", [0, 2]) == [restored["inventories"]["spa"][0], restored["inventories"]["spa"][2]]
+    assert view.feature_values("syllabic", [0]) == [table.feature_categories("syllabic")[0]]
+    with pytest.raises(ValueError, match="Missing phonemes"):
+        table.subset(["a", "nope"])
