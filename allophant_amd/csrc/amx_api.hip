@@ -662,8 +662,7 @@ static void select_inventory(amx_handle h, int i) {
     h->out_all_dev = e.out_all_dev;
 }
 
-// builds a new cache entry on `s`: every buffer is fresh, so nothing in flight can be reading it; the uploads come from
-// pageable host memory (staged by the runtime before the call returns) and are ordered before later work on `s`
+// builds a new cache entry on `s`: every buffer is fresh, so nothing in flight can be reading it
 static int install_inventory(amx_handle h, std::vector<int64_t>&& key, const std::vector<int64_t>& idx, int P1, int features,
                              hipStream_t s) {
     int slot = -1;
@@ -705,7 +704,9 @@ static int install_inventory(amx_handle h, std::vector<int64_t>&& key, const std
         launch_compose(h->prec, h->emb, E, e.idx_dev, P1, features, e.composed_f32, e.composed_w, (int64_t)P1 * E, E, s);
         if (hipGetLastError() != hipSuccess) return fail_free(AMX_EHIP, "compose kernel launch failed");
     }
-    // the staged uploads above read host vectors that die with this call: HIP stages pageable sources before returning
+    // the uploads above read pageable host vectors that die with this call; a new inventory is a rare event (the cache
+    // serves repeats), so the call simply waits for them instead of relying on the runtime's staging behaviour
+    if (hipStreamSynchronize(s) != hipSuccess) return fail_free(AMX_EHIP, "inventory upload failed");
     e.key = std::move(key);
     select_inventory(h, slot);
     return AMX_OK;

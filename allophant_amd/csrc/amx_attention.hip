@@ -23,6 +23,7 @@
 // Masked keys (t' >= frame_len[n]) get -inf before the softmax; key tiles past the utterance end are skipped (their
 // probabilities are exactly 0 in the reference too: finfo.min bias underflows exp to 0).
 #include "amx_common.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace amx {
@@ -229,8 +230,13 @@ __global__ __launch_bounds__(WAVES * 64, AMX_ATTN_OCC) void attn_kernel(const At
                     O[dt] = mfma32(vf.v, ph.v, O[dt]);
                 }
             }
-        // tile kt+1 has landed (this wave's pieces) and everyone is done reading tile kt
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // tile kt+1 has landed (this wave's pieces) and this wave's LDS reads of tile kt have RETURNED: the first thing any
+        // wave does after the barrier is to DMA tile kt+2 over tile kt, so a read still in flight at the barrier could see
+        // the new tile (cdna_hip_programming.md, "restage a buffer one phase after its last ds_read only when an lgkmcnt
+        // before the barrier retired those reads").  Without the lgkmcnt(0) hipcc leaves the V reads of the last P.V group
+        // in flight across the barrier: one 32-query block in ~1000 launches came out with a few keys of the wrong tile
+        // (4 x 60 s batches, tools/stress_repro.py).
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     };
 
@@ -275,12 +281,30 @@ void launch_attn(const AttnParams& p, hipStream_t stream) {
 
 }  // namespace
 
+template <typename T, int NT>
+void launch_attn_any(const AttnParams& p, hipStream_t stream) {
+    // Short batches (e.g. 4 x 10 s: 64 (utterance, head) pairs x 2 blocks of 256 queries) leave most CUs without a
+    // workgroup while the busy ones run two waves per SIMD: with 128-query workgroups of 4 waves the same waves spread over
+    // twice as many CUs, one per SIMD.  Each query's arithmetic is identical in both forms (bitwise equal outputs).
+    static int cus_of[MAX_DEVICES] = {};
+    int& cus = cus_of[current_device()];
+    if (!cus) {
+        hipDeviceProp_t prop;
+        cus = hipGetDeviceProperties(&prop, current_device()) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int64_t wg8 = (int64_t)p.N * p.H * ((p.T + 255) / 256);
+    static const int force = getenv("AMX_ATTN_WAVES") ? atoi(getenv("AMX_ATTN_WAVES")) : 0;  // developer A/B switch
+    const bool small = force ? force == 4 : wg8 * 2 <= cus;
+    if (small) launch_attn<T, NT, 4>(p, stream);
+    else launch_attn<T, NT, 8>(p, stream);
+}
+
 void launch_attention(int prec, const AttnParams& p, hipStream_t stream) {
     switch (prec) {
-        case PREC_BF16: launch_attn<bf16, 1, 8>(p, stream); break;
-        case PREC_F16: launch_attn<f16, 1, 8>(p, stream); break;
-        case PREC_BF16X3: launch_attn<bf16, 2, 8>(p, stream); break;
-        default: launch_attn<f16, 2, 8>(p, stream); break;
+        case PREC_BF16: launch_attn_any<bf16, 1>(p, stream); break;
+        case PREC_F16: launch_attn_any<f16, 1>(p, stream); break;
+        case PREC_BF16X3: launch_attn_any<bf16, 2>(p, stream); break;
+        default: launch_attn_any<f16, 2>(p, stream); break;
     }
 }
 

@@ -253,7 +253,9 @@ int dma_preferred_shape(int NT, const GemmParams& p) {
     if (!shape) return 0;
     if (p.M < 768) return shape;
     const int pp_tiles = ((p.N + pp::BN - 1) / pp::BN) * ((p.M + 127) / 128);
-    if (p.M < max_rows && pp_tiles * 2 <= device_cus()) return shape;
+    // (K = 4096 products stay on the ping-pong kernel: its K chunks beat a 128-sub-step loop per tile -- tools/gemm_bench
+    // small, M = 1996: out-proj 40.6 -> 29.5 us on DMA tiles, FFN2 66.1 -> 74.8 us)
+    if (p.M < max_rows && p.K <= 2048 && pp_tiles * 2 <= device_cus()) return shape;
     return 0;
 }
 

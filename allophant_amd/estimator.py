@@ -293,9 +293,10 @@ class Estimator:
                     part_total = sum(T.value * n * c for c in blocks.values())
                     part = torch.empty(part_total, dtype=torch.float32, device=self._device)
                     part_lengths = torch.empty(n, dtype=torch.int64)
+                    slice_lengths = lengths[lo:hi].contiguous()  # named: must outlive the call that reads its storage
                     code = self._lib.amx_forward(
                         self._handle, C.c_void_p(audio[lo:hi].data_ptr()),
-                        C.cast(lengths[lo:hi].contiguous().data_ptr(), C.POINTER(C.c_int64)), n, L,
+                        C.cast(slice_lengths.data_ptr(), C.POINTER(C.c_int64)), n, L,
                         C.c_void_p(part.data_ptr()), C.cast(part_lengths.data_ptr(), C.POINTER(C.c_int64)),
                         flags | _lib.FLAG_PADDED, C.c_void_p(stream))
                     _lib.check(self._lib, self._handle, code)

@@ -1,8 +1,8 @@
 """Copies the summaries of tools/profile_bench.sh runs (gpurun_out/prof_<tag>/) into profiles/ and rebuilds
-profiles/r01_gemm_traffic.json, the per-launch HBM traffic of the ping-pong GEMM that bench.py reports as
-`roofline.traffic`.
+profiles/<round>_traffic.json: the per-launch HBM traffic of the ping-pong GEMM that bench.py reports as
+`roofline.traffic`, and the traffic of the conv-stage kernels (`roofline.conv_stage.*.traffic`).
 
-    python tools/collect_profiles.py r01 f16x3:prof_r01_f16x3 bf16:prof_r01_bf16
+    python tools/collect_profiles.py r02 f16x3:prof_r02_f16x3 bf16:prof_r02_bf16
 
 Correction applied (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts half of the bytes of 16-byte-per-lane streaming
 reads (global_load and buffer_load ... lds alike), so it is doubled; WRITE_SIZE is exact; both are in KiB; hits in the
@@ -45,11 +45,18 @@ for arg in sys.argv[2:]:
                   open(dst + "_pmc_mfma.json", "w"), indent=1)
         for kernel, row in sorted(mfma.items(), key=lambda kv: -kv[1]["mfma_busy_frac"])[:4]:
             print(f"  mfma busy {row['mfma_busy_frac']:.3f}  {kernel[-70:]}")
-    gemm = [v for k, v in merged.items() if "gemm_pp_kernel" in k]
+    # the dominant kernel: the 256-row instance of the ping-pong GEMM (the 128-row instance is the last conv layer)
+    gemm = [v for k, v in merged.items() if "gemm_pp_kernel" in k and ("Li8EE" in k or ",8>" in k.replace(" ", ""))] or \
+           [v for k, v in merged.items() if "gemm_pp_kernel" in k]
     if not gemm:
         raise SystemExit(f"no gemm_pp_kernel counters in {src}")
-    fetch_kb = sum(v["FETCH_SIZE"]["sum"] for v in gemm) / sum(v["FETCH_SIZE"]["dispatches"] for v in gemm)
-    write_kb = sum(v["WRITE_SIZE"]["sum"] for v in gemm) / sum(v["WRITE_SIZE"]["dispatches"] for v in gemm)
+
+    def per_dispatch(rows):
+        fetch = sum(v["FETCH_SIZE"]["sum"] for v in rows) / sum(v["FETCH_SIZE"]["dispatches"] for v in rows)
+        write = sum(v["WRITE_SIZE"]["sum"] for v in rows) / sum(v["WRITE_SIZE"]["dispatches"] for v in rows)
+        return fetch, write
+
+    fetch_kb, write_kb = per_dispatch(gemm)
     traffic[precision] = {
         "hbm_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,
         "fetch_size_kb_raw": fetch_kb,
@@ -60,5 +67,19 @@ for arg in sys.argv[2:]:
         "source": f"profiles/{round_tag}_{precision}_pmc_hbm.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, "
                   "bench.py --steps 2)",
     }
+    conv0 = [v for k, v in merged.items() if "conv0_kernel" in k]
+    if conv0:
+        f, w = per_dispatch(conv0)
+        # conv0 reads fp32 audio with 4-byte-per-lane loads (FETCH_SIZE calibration for that width is not in the guide: the
+        # raw and the doubled figure are both kept) and writes 16-byte-per-lane plane stores (WRITE_SIZE exact)
+        traffic[precision]["conv0_hbm_bytes_per_launch"] = (2.0 * f + w) * 1024.0
+        traffic[precision]["conv0_fetch_size_kb_raw"] = f
+        traffic[precision]["conv0_write_size_kb"] = w
+    ln = [v for k, v in merged.items() if "gemm_ln_kernel" in k]
+    if ln:
+        f = sum(v["FETCH_SIZE"]["sum"] for v in ln)
+        w = sum(v["WRITE_SIZE"]["sum"] for v in ln)
+        steps = max(1, ln[0]["FETCH_SIZE"]["dispatches"] // 5)  # 5 launches (conv layers 1-5) per step
+        traffic[precision]["gemm_ln_hbm_bytes_per_step"] = (2.0 * f + w) * 1024.0 / steps
     print(precision, {k: round(v, 1) if isinstance(v, float) else v for k, v in traffic[precision].items() if k != "correction"})
-json.dump(traffic, open(os.path.join(ROOT, "profiles", f"{round_tag}_gemm_traffic.json"), "w"), indent=1)
+json.dump(traffic, open(os.path.join(ROOT, "profiles", f"{round_tag}_traffic.json"), "w"), indent=1)

@@ -1,0 +1,51 @@
+"""Developer diagnostic: one long utterance alone / inside a padded slice of a larger batch, under both GEMM routings, each
+against the CPU oracle (per-output max-abs error on valid frames).  Imports the oracle: a developer tool, not product."""
+import os
+import subprocess
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import bench
+from allophant_amd import synthetic
+from allophant_amd.estimator import Batch, Estimator
+
+mode = sys.argv[1] if len(sys.argv) > 1 else "driver"
+seconds = float(os.environ.get("DIAG_SECONDS", "40"))
+spec = bench.build_spec()
+state = synthetic.make_state_dict(spec, seed=0)
+tfi = synthetic.make_inventory(spec, 27, seed=0)
+L = int(seconds * 16000)
+n_batch = int(os.environ.get("DIAG_BATCH", "4"))
+audio, lengths = synthetic.make_audio(n_batch, L, seed=17, ragged=True)
+i = n_batch - 1
+n_i = int(lengths[i])
+if mode == "oracle":
+    from oracle import allophant_oracle as O
+    ref, ref_len = O.predict(audio[i:i + 1, :n_i].contiguous(), lengths[i:i + 1], state, spec, tfi, synthetic.category_offsets(spec))
+    torch.save({k: v[:, 0] for k, v in ref.items()}, "/tmp/diag_ref.pt")
+    sys.exit(0)
+if mode == "driver":
+    subprocess.check_call([sys.executable, __file__, "oracle"])
+    for env in ({}, {"AMX_DMA_MAX_ROWS": "768"}):
+        e = dict(os.environ, **env)
+        subprocess.check_call([sys.executable, __file__, "gpu"], env=e)
+    sys.exit(0)
+ref = torch.load("/tmp/diag_ref.pt")
+est = Estimator(spec, state, "cuda:0", "f16x3")
+solo = est.predict(Batch(audio[i:i + 1, :n_i].contiguous().cuda(), lengths[i:i + 1], torch.zeros(1, dtype=torch.long)), tfi)
+t_i = int(solo.lengths[0])
+full = est.predict(Batch(audio.cuda(), lengths, torch.zeros(n_batch, dtype=torch.long)), tfi)
+print("routing", os.environ.get("AMX_DMA_MAX_ROWS", "default"), "frames", t_i)
+for name, pred, col in (("solo", solo, 0), ("batch", full, i)):
+    errs = {k: (pred.outputs[k][:t_i, col].cpu() - ref[k][:t_i]).abs().max().item() for k in ref}
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+    print(f"  {name:6s} vs oracle:", " ".join(f"{k}={v:.2e}" for k, v in worst))
+d = {k: (solo.outputs[k][:t_i, 0] - full.outputs[k][:t_i, i]).abs().max().item() for k in ref}
+print("  solo vs batch:", " ".join(f"{k}={v:.2e}" for k, v in sorted(d.items(), key=lambda kv: -kv[1])[:4]))
+# where along time is the phoneme difference?
+diff = (solo.outputs["phoneme"][:t_i, 0] - full.outputs["phoneme"][:t_i, i]).abs().max(-1).values.cpu()
+top = torch.topk(diff, 5)
+print("  phoneme diff top frames:", top.indices.tolist(), [f"{v:.1e}" for v in top.values.tolist()])
+est.close()
