@@ -34,6 +34,8 @@ int device_cus() {
     if (!cus) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        // developer switch: size the persistent grids for a CU-masked stream (tools/two_stream_probe.py)
+        if (getenv("AMX_FORCE_CUS") && atoi(getenv("AMX_FORCE_CUS")) > 0) cus = atoi(getenv("AMX_FORCE_CUS"));
         if (cus <= 0) cus = 256;
         cus -= cus % 8;  // the tile order assumes sequence numbers i and i + grid share an XCD
         if (cus < 8) cus = 8;

@@ -186,6 +186,11 @@ def main():
     # AMX_BENCH_FORCE_DIST=1 (developer switch): run the RCCL gather path with a one-rank group, so that the collective
     # code is exercised on a single-GPU box (launch under torch.distributed.run --nproc-per-node 1)
     use_dist = world > 1 or os.environ.get("AMX_BENCH_FORCE_DIST") == "1"
+    # stdout carries exactly ONE JSON line: RCCL prints a version banner to stdout when its first communicator comes up, so
+    # everything before the final print goes to stderr (file descriptor 1 is pointed at stderr until then)
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     if use_dist:
         dist.init_process_group("nccl", device_id=device)
 
@@ -401,8 +406,13 @@ def main():
             result["cpu_baseline"] = cpu_baseline(spec, state, tfi, args.cpu_sample, length)
         else:
             result["cpu_baseline"] = None
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    os.close(saved_stdout)
+    if rank == 0:
         print(json.dumps(result), flush=True)
     if use_dist:
+        os.dup2(2, 1)  # teardown chatter, if any, stays off stdout too
         dist.destroy_process_group()
 
 
