@@ -1045,6 +1045,13 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     {
         { Timed t_(h, AMX_KC_OTHER); launch_posconv_pack(prec, (const float*)hbuf, N, T, D, c.pos_groups, c.pos_kernel / 2, Tpad, hg,
                             (int64_t)N * Tpad * D, s); }
+        // AMX_NO_POSCONV_WINDOW=1: developer A/B switch (grouped implicit GEMM on the tile kernels instead)
+        static const bool no_window = getenv("AMX_NO_POSCONV_WINDOW") && atoi(getenv("AMX_NO_POSCONV_WINDOW")) != 0;
+        if (!no_window && posconv_window_eligible(D, c.pos_groups, c.pos_kernel, N, T, Tpad, (int64_t)N * Tpad * D)) {
+            Timed t_(h, AMX_KC_GEMM_TILE);
+            launch_posconv_window(prec, hg, (int64_t)N * Tpad * D, h->pos_w, (int64_t)D * cg * c.pos_kernel,
+                                  (int64_t)cg * c.pos_kernel, h->pos_b, (float*)hbuf, N, T, Tpad, D, c.pos_groups, c.pos_kernel, s);
+        } else {
         GemmParams g{};
         g.A = hg; g.a_plane = (int64_t)N * Tpad * D; g.lda = cg; g.rows_per_batch = T; g.a_batch_stride = (int64_t)Tpad * cg;
         g.za = (int64_t)N * Tpad * cg;
@@ -1054,6 +1061,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         g.scale = 1.f; g.bias = h->pos_b; g.zbias = cg; g.act = 1;
         g.residual = (const float*)hbuf; g.ldr = D; g.out_f32 = (float*)hbuf; g.ldo = D; g.zout = cg;
         { Timed t_(h, AMX_KC_GEMM_TILE); launch_gemm_grouped(prec, g, c.pos_groups, s); }
+        }
     }
     // ---- transformer encoder (pre-LN) ----
     const int64_t xp_plane = M * D;

@@ -31,15 +31,18 @@ namespace amx {
 namespace {
 
 constexpr int DH = 64;
-constexpr int KT = 64;             // keys per tile
-constexpr int TILE = KT * 128;     // bytes of one K or V tile of one plane
 constexpr float DEFER_THR = 8.0f;  // log2 units
 
+// waves per SIMD the register allocation must allow: two 8-wave workgroups or four 4-wave / 32-key workgroups per CU -> 4;
+// two 4-wave / 64-key workgroups -> 2
 #ifndef AMX_ATTN_OCC
-#define AMX_ATTN_OCC ((WAVES * 64) / 128)
+#define AMX_ATTN_OCC ((WAVES == 8 || KT == 32) ? 4 : 2)
 #endif
-template <typename T, int NT, int WAVES>
+// KT = keys per tile (64; a 32-key instance with four 4-wave workgroups per CU was 5 % slower at 32 x 10 s)
+template <typename T, int NT, int WAVES, int KT>
 __global__ __launch_bounds__(WAVES * 64, AMX_ATTN_OCC) void attn_kernel(const AttnParams p) {
+    constexpr int TILE = KT * 128;     // bytes of one K or V tile of one plane
+    constexpr int NC = KT / 32;        // 32-key blocks per tile
     typedef typename Vec8<T>::type V8;
     typedef typename Vec4<T>::type V4;
     typedef short s16x4 __attribute__((__vector_size__(8)));
@@ -47,7 +50,8 @@ __global__ __launch_bounds__(WAVES * 64, AMX_ATTN_OCC) void attn_kernel(const At
     typedef __attribute__((address_space(3))) s16x4* lds_s4_t;
     constexpr int QB = WAVES * 32;
     constexpr int STAGE = NT * 2 * TILE;  // [plane][K tile | V tile]
-    constexpr int PPW = 8 / WAVES;        // DMA pieces per wave, per tile and plane (K and V each)
+    constexpr int PPW = (KT / 8) / WAVES;  // DMA pieces (8 rows x 128 B) per wave, per tile and plane (K and V each)
+    static_assert(PPW >= 1 && PPW * WAVES * 8 == KT, "whole DMA pieces per wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -133,10 +137,10 @@ __global__ __launch_bounds__(WAVES * 64, AMX_ATTN_OCC) void attn_kernel(const At
         const unsigned char* sb = smem + ST * STAGE;
 
         // ---- S^T = K . Q^T : X[c][r] = score(key = kb + 32c + (r&3) + 8(r>>2) + 4hh, query), log2 units ----
-        f32x16 X[2];
+        f32x16 X[NC];
         const float neg_m = -m_run;
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < NC; ++c) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) X[c][r] = neg_m;
 #pragma unroll
@@ -154,20 +158,28 @@ __global__ __launch_bounds__(WAVES * 64, AMX_ATTN_OCC) void attn_kernel(const At
         if (kb + KT > klen) {  // only the last tile holds masked keys (wave-uniform branch)
             const int rem = klen - kb - 4 * hh;  // keys of this lane's rows left in the utterance
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
+            for (int c = 0; c < NC; ++c)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) X[c][r] = 32 * c + (r & 3) + 8 * (r >> 2) < rem ? X[c][r] : -INFINITY;
         }
         // scores are relative to the running maximum (the accumulators start at -m_run): tile maximum by v_max3 trees
         float mx;
-        {
+        if constexpr (NC == 2) {
             float t0 = fmaxf(fmaxf(X[0][0], X[0][1]), X[0][2]), t1 = fmaxf(fmaxf(X[1][0], X[1][1]), X[1][2]);
 #pragma unroll
             for (int r = 3; r + 1 < 16; r += 2) {
                 t0 = fmaxf(fmaxf(t0, X[0][r]), X[0][r + 1]);
                 t1 = fmaxf(fmaxf(t1, X[1][r]), X[1][r + 1]);
             }
-            mx = fmaxf(fmaxf(t0, t1), fmaxf(X[0][15], X[1][15]));
+            mx = fmaxf(fmaxf(t0, t1), fmaxf(X[0][15], X[NC - 1][15]));
+        } else {
+            float t0 = fmaxf(fmaxf(X[0][0], X[0][1]), X[0][2]), t1 = fmaxf(fmaxf(X[0][3], X[0][4]), X[0][5]);
+#pragma unroll
+            for (int r = 6; r + 3 < 16; r += 4) {
+                t0 = fmaxf(fmaxf(t0, X[0][r]), X[0][r + 1]);
+                t1 = fmaxf(fmaxf(t1, X[0][r + 2]), X[0][r + 3]);
+            }
+            mx = fmaxf(fmaxf(t0, t1), fmaxf(X[0][14], X[0][15]));
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         // wave-uniform; both lane halves of a query see the same mx.  The first tile always takes its own maximum (m_run
@@ -180,13 +192,13 @@ __global__ __launch_bounds__(WAVES * 64, AMX_ATTN_OCC) void attn_kernel(const At
 #pragma unroll
             for (int r = 0; r < 16; ++r) { O[0][r] *= alpha; O[1][r] *= alpha; }
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
+            for (int c = 0; c < NC; ++c)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) X[c][r] -= d;
         }
         f32x2 ps = {0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < NC; ++c)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 const f32x2 e = {__builtin_amdgcn_exp2f(X[c][r]), __builtin_amdgcn_exp2f(X[c][r + 1])};
@@ -198,7 +210,7 @@ __global__ __launch_bounds__(WAVES * 64, AMX_ATTN_OCC) void attn_kernel(const At
 
         // ---- O^T += V^T . P : P's accumulator registers are the B operand ----
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < NC; ++c)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 // hi/lo planes of 8 probabilities, two at a time on the packed converts (exp2 results are plain register
@@ -268,15 +280,15 @@ __global__ __launch_bounds__(WAVES * 64, AMX_ATTN_OCC) void attn_kernel(const At
     }
 }
 
-template <typename T, int NT, int WAVES>
+template <typename T, int NT, int WAVES, int KT>
 void launch_attn(const AttnParams& p, hipStream_t stream) {
-    constexpr int lds = 2 * NT * 2 * TILE;
+    constexpr int lds = 2 * NT * 2 * KT * 128;
     static OncePerDevice attr;
     if (attr.first())
-        (void)hipFuncSetAttribute((const void*)attn_kernel<T, NT, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)attn_kernel<T, NT, WAVES, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const int qblocks = (p.T + WAVES * 32 - 1) / (WAVES * 32);
     dim3 grid((unsigned)(8 * ((p.N * p.H + 7) / 8) * qblocks));
-    hipLaunchKernelGGL((attn_kernel<T, NT, WAVES>), grid, dim3(WAVES * 64), lds, stream, p);
+    hipLaunchKernelGGL((attn_kernel<T, NT, WAVES, KT>), grid, dim3(WAVES * 64), lds, stream, p);
 }
 
 }  // namespace
@@ -295,8 +307,8 @@ void launch_attn_any(const AttnParams& p, hipStream_t stream) {
     const int64_t wg8 = (int64_t)p.N * p.H * ((p.T + 255) / 256);
     static const int force = getenv("AMX_ATTN_WAVES") ? atoi(getenv("AMX_ATTN_WAVES")) : 0;  // developer A/B switch
     const bool small = force ? force == 4 : wg8 * 2 <= cus;
-    if (small) launch_attn<T, NT, 4>(p, stream);
-    else launch_attn<T, NT, 8>(p, stream);
+    if (small) launch_attn<T, NT, 4, 64>(p, stream);
+    else launch_attn<T, NT, 8, 64>(p, stream);
 }
 
 void launch_attention(int prec, const AttnParams& p, hipStream_t stream) {

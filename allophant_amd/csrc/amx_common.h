@@ -213,6 +213,12 @@ void launch_rownorm(int prec, const float* x, int64_t ldx, int64_t M, int D, con
 void launch_posconv_pack(int prec, const float* h, int N, int T, int D, int G, int pad_front, int Tpad, void* out,
                          int64_t out_plane, hipStream_t s);
 
+// window-resident grouped positional convolution (amx_posconv.hip): h[n, t, g*64 + co] += gelu(bias + conv) from the padded
+// image [G][N][Tpad][64] and the weights [G][64][taps * 64]; eligible when hidden / groups == 64 and taps <= 128
+bool posconv_window_eligible(int D, int G, int taps, int N, int Tn, int Tpad, int64_t image_plane);
+void launch_posconv_window(int prec, const void* image, int64_t image_plane, const void* weights, int64_t w_plane, int64_t ldw,
+                           const float* bias, float* h, int N, int Tn, int Tpad, int D, int G, int taps, hipStream_t s);
+
 struct ConcatPart {
     int type;     // 0: fp32 hidden rows -> planes; 1: softmax over logits columns
     int src_col;  // column offset in the logits buffer (type 1)

@@ -21,7 +21,8 @@ KERNEL_CLASSES = ["gemm_pp", "gemm_tile", "attention", "rownorm", "conv0", "othe
 DEP_OUTPUT = -1
 
 LIB_NAME = "liballophant_amx.so"
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+# AMX_LIB_PATH: developer switch (A/B builds of the library side by side); the default is the in-tree build
+LIB_PATH = os.environ.get("AMX_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 # every symbol include/allophant_amx.h declares
 EXPORTS = [
