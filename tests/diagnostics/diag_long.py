@@ -1,10 +1,10 @@
 """Developer diagnostic: one long utterance alone / inside a padded slice of a larger batch, under both GEMM routings, each
-against the CPU oracle (per-output max-abs error on valid frames).  Imports the oracle: a developer tool, not product."""
+against the CPU oracle (per-output max-abs error on valid frames).  Lives under tests/ because it runs the CPU oracle (test infrastructure)."""
 import os
 import subprocess
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
 import bench
