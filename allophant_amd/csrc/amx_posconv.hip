@@ -5,16 +5,18 @@
 // of output frame t is the window of frames t .. t + taps - 1: consecutive frames share all but one row of it, and the
 // generic tile kernel re-reads every frame once per tap from L2 (128 x).  Here a workgroup keeps the WINDOW of its 256
 // output frames resident in LDS -- 256 + taps - 1 rows of 128 bytes per plane, DMA-ed once -- and streams only the weights:
-// per tap one 64 x 64 slice (8 KiB per plane) through a 3-stage LDS-DMA ring.  The A fragments of tap j are the fragment
+// per tap one 64 x 64 slice (8 KiB per plane) through a 4-stage LDS-DMA ring, two taps per barrier interval.  The A fragments of tap j are the fragment
 // reads of tap 0 shifted down by j rows.
 //   * 8 waves, wave w owns output frames 32w .. 32w+31 (2 x 4 accumulator fragments of v_mfma_f32_16x16x32; W is the first
 //     operand, so a lane ends up with 4 consecutive output channels of one frame);
 //   * bank swizzle: 16-byte chunk ^= (row >> 1) & 7 on the DMA source address and on the fragment reads; 16 consecutive
 //     rows give 16 distinct (row parity, chunk) pairs whatever the first row, so the shifted reads stay conflict-free;
-//   * ring protocol per tap: this wave's pieces of tap j have landed (counted vmcnt leaving tap j+1 in flight) and its LDS
-//     reads of tap j-1 have returned (lgkmcnt(0)) -> s_barrier -> DMA of tap j+2 into the stage tap j-1 was read from ->
-//     multiply tap j.  (A read left in flight across the barrier could see the refill: the race found in the attention ring.)
-// Requires hidden / groups == 64 and taps <= 128; other shapes stay on the implicit-GEMM path.
+//   * ring protocol per pair of taps (j, j+1): this wave's pieces of both have landed (vmcnt(0): nothing younger is in
+//     flight) and its LDS reads of the previous pair have returned (lgkmcnt(0)) -> s_barrier -> DMA of taps j+2, j+3 into the
+//     two stages the previous pair was read from -> multiply taps j and j+1.  (A read left in flight across the barrier
+//     could see the refill: the race found in the attention ring.)  One barrier per pair: with one per tap the waves sat
+//     parked at the barrier for 48 % of their cycles (profiles/r02_wave_state_pmc.txt).
+// Requires hidden / groups == 64 and an even number of taps <= 128; other shapes stay on the implicit-GEMM path.
 #include "amx_common.h"
 
 namespace amx {
@@ -25,7 +27,7 @@ constexpr int PC_ROWS = 256;                        // output frames per workgro
 constexpr int PC_CG = 64;                           // channels per group
 constexpr int PC_MAX_TAPS = 128;
 constexpr int PC_WIN = PC_ROWS + PC_MAX_TAPS;       // window rows reserved per plane (256 + taps - 1 used)
-constexpr int PC_STAGES = 3;
+constexpr int PC_STAGES = 4;
 constexpr int PC_WTAP = PC_CG * 128;                // bytes of one tap's weights of one plane: 64 rows x 128 B
 
 template <typename T, int NT>
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(512, 2) void posconv_window_kernel(const T* __restr
                                                      pl * w_plane_b + (uint32_t)tap * 128, 0, 0);
     };
     stage_w(0);
-    if (taps > 1) stage_w(1);
+    stage_w(1);
 
     // ---- fragment read offsets ----
     // A fragment (mi, kk) of tap j: window row 32 wave + 16 mi + (lane & 15) + j, logical chunk 4 kk + (lane >> 4)
@@ -100,13 +102,7 @@ __global__ __launch_bounds__(512, 2) void posconv_window_kernel(const T* __restr
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int j = 0; j < taps; ++j) {
-        // tap j's weights (and, for j = 0, the window) have landed: only the pieces of tap j + 1 may still be in flight
-        if (j + 1 < taps) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NT) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");  // no LDS read of tap j is scheduled above the barrier
-        if (j + 2 < taps) stage_w(j + 2);
+    auto multiply_tap = [&](int j) {
         const unsigned char* sw = s_w + (j % PC_STAGES) * (NT * PC_WTAP);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -133,6 +129,15 @@ __global__ __launch_bounds__(512, 2) void posconv_window_kernel(const T* __restr
                     acc[ni][mi] = mfma16(wf[0][ni], af[0][mi], acc[ni][mi]);
                 }
         }
+    };
+    for (int j = 0; j < taps; j += 2) {  // taps is even
+        // taps j and j + 1 (and, for j = 0, the window) have landed: nothing younger has been issued yet
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");  // no LDS read of this pair is scheduled above the barrier
+        if (j + 2 < taps) { stage_w(j + 2); stage_w(j + 3); }
+        multiply_tap(j);
+        multiply_tap(j + 1);
     }
 
     // ---- epilogue: h += gelu(acc + bias); acc[ni][mi][r] is frame 16 mi + (lane & 15), channel 16 ni + 4 (lane >> 4) + r ----
@@ -172,7 +177,7 @@ void launch_posconv_t(const void* image, int64_t image_plane, const void* weight
 }  // namespace
 
 bool posconv_window_eligible(int D, int G, int taps, int N, int Tn, int Tpad, int64_t image_plane) {
-    if (G < 1 || D % G || D / G != PC_CG || taps < 1 || taps > PC_MAX_TAPS || Tpad < Tn + taps - 1) return false;
+    if (G < 1 || D % G || D / G != PC_CG || taps < 2 || taps % 2 || taps > PC_MAX_TAPS || Tpad < Tn + taps - 1) return false;
     // 32-bit byte offsets inside one (group, utterance) image and one group's weights; the plane offset rides in soffset
     if ((int64_t)Tpad * 128 >= (int64_t)0x7FFFFFFF || image_plane * 2 >= (int64_t)0xFFFFFF00) return false;
     if ((int64_t)PC_CG * taps * PC_CG * 2 * PC_CG >= (int64_t)0x7FFFFFFF) return false;
