@@ -547,8 +547,39 @@ __global__ __launch_bounds__(256) void logsoftmax_out_kernel(const OutDesc* __re
     if (row >= (int64_t)N * T) return;
     const int n = (int)(row / T), t = (int)(row % T);
     const float* src_row = logits + row * ld;
+    // narrow outputs (the attribute classifiers: 4 classes each): one LANE per output, everything lane-local -- a wave
+    // reduction per 4-class output (36 of them per frame) made this kernel 20x slower than its 11 MB of traffic
+    constexpr int NARROW = 8;
+    for (int o0 = 0; o0 < n_out; o0 += 64) {
+        const int o = o0 + lane;
+        if (o < n_out) {
+            const OutDesc d = descs[o];
+            if (d.C <= NARROW) {
+                const float* src = src_row + d.col;
+                float* dst = out + (int64_t)T * N * d.prefix + ((int64_t)t * N + n) * d.C;
+                float v[NARROW];
+#pragma unroll
+                for (int c = 0; c < NARROW; ++c) v[c] = c < d.C ? src[c] : -INFINITY;
+                float lse = 0.f;
+                if (log_probs) {
+                    float m = v[0];
+#pragma unroll
+                    for (int c = 1; c < NARROW; ++c) m = fmaxf(m, v[c]);
+                    float sum = 0.f;
+#pragma unroll
+                    for (int c = 0; c < NARROW; ++c) sum += c < d.C ? expf(v[c] - m) : 0.f;
+                    lse = m + logf(sum);
+                }
+#pragma unroll
+                for (int c = 0; c < NARROW; ++c)
+                    if (c < d.C) dst[c] = v[c] - lse;
+            }
+        }
+    }
+    // wide outputs (phoneme / phone inventories): the whole wave per output
     for (int o = 0; o < n_out; ++o) {
         const OutDesc d = descs[o];
+        if (d.C <= NARROW) continue;
         const float* src = src_row + d.col;
         float* dst = out + (int64_t)T * N * d.prefix + ((int64_t)t * N + n) * d.C;
         float lse = 0.f;
