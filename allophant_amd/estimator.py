@@ -87,6 +87,36 @@ class CTCHypothesis(NamedTuple):
     timesteps: Tensor
 
 
+class Decoded(NamedTuple):
+    """Greedy CTC alignments of a batch, one row per output: ``tokens`` / ``timesteps`` ``[O, N, T]`` int64 of which the
+    first ``counts[o, n]`` entries are valid, ``counts`` ``[O, N]`` int32, ``scores`` ``[O, N]`` fp32 (sum of the per-frame
+    maxima, predictions.py:205).  Device tensors when produced by ``Estimator.greedy_decode_device``."""
+    names: List[str]
+    tokens: Tensor
+    timesteps: Tensor
+    counts: Tensor
+    scores: Tensor
+
+    def select(self, names: List[str]) -> "Decoded":
+        rows = [self.names.index(name) for name in names]
+        index = torch.tensor(rows, dtype=torch.long, device=self.tokens.device)
+        return Decoded(list(names), self.tokens.index_select(0, index), self.timesteps.index_select(0, index),
+                       self.counts.index_select(0, index), self.scores.index_select(0, index))
+
+    def hypotheses(self) -> Dict[str, List[List[CTCHypothesis]]]:
+        """Host form: per output and utterance ``[CTCHypothesis(tokens, [], score, timesteps)]`` like the reference."""
+        counts_h, scores_h = self.counts.cpu(), self.scores.cpu()
+        tokens_h, timesteps_h = self.tokens.cpu(), self.timesteps.cpu()
+        result: Dict[str, List[List[CTCHypothesis]]] = {}
+        for o, name in enumerate(self.names):
+            hyps = []
+            for n in range(counts_h.shape[1]):
+                k = int(counts_h[o, n])
+                hyps.append([CTCHypothesis(tokens_h[o, n, :k].clone(), [], float(scores_h[o, n]), timesteps_h[o, n, :k].clone())])
+            result[name] = hyps
+        return result
+
+
 def _spec_to_structs(spec: Dict[str, Any], precision: str):
     cfg = _lib.AmxConfig()
     cfg.abi_version = _lib.AMX_ABI_VERSION
@@ -317,9 +347,10 @@ class Estimator:
             outputs[d.name.decode()] = flat[d.offset: d.offset + T.value * N * c].view(T.value, N, c)
         return Predictions(outputs, out_lengths.to(batch.lengths.device), flat, (N, L), self._inventory)
 
-    def greedy_decode(self, predictions: Predictions) -> Dict[str, List[List[CTCHypothesis]]]:
+    def greedy_decode_device(self, predictions: Predictions) -> "Decoded":
         """On-device ``GreedyCTCDecoder`` over every output of ``predictions`` (reference predictions.py:194-207 applied
-        per classifier as in run.py:767-774).  Only token ids / timesteps / scores cross PCIe."""
+        per classifier as in run.py:767-774); the result stays in HBM (``Decoded``: no host copy, no synchronisation), which
+        is what the data-parallel path gathers instead of log-probabilities (``parallel.gather_decoded``)."""
         if predictions._flat is None or predictions._geometry is None:
             raise ValueError("predictions were not produced by this estimator")
         N, L = predictions._geometry
@@ -342,18 +373,12 @@ class Estimator:
                 C.c_void_p(timesteps.data_ptr()), C.c_void_p(counts.data_ptr()), C.c_void_p(scores.data_ptr()),
                 C.c_void_p(stream))
             _lib.check(self._lib, self._handle, code)
-            counts_h = counts.cpu()
-            scores_h = scores.cpu()
-            tokens_h = tokens.cpu()
-            timesteps_h = timesteps.cpu()
-        result: Dict[str, List[List[CTCHypothesis]]] = {}
-        for o, name in enumerate(names):
-            hyps = []
-            for n in range(N):
-                k = int(counts_h[o, n])
-                hyps.append([CTCHypothesis(tokens_h[o, n, :k].clone(), [], float(scores_h[o, n]), timesteps_h[o, n, :k].clone())])
-            result[name] = hyps
-        return result
+        return Decoded(names, tokens, timesteps, counts, scores)
+
+    def greedy_decode(self, predictions: Predictions) -> Dict[str, List[List[CTCHypothesis]]]:
+        """``greedy_decode_device`` fetched to the host as the reference's hypothesis lists.  Only token ids / timesteps /
+        scores cross PCIe."""
+        return self.greedy_decode_device(predictions).hypotheses()
 
     def debug_fetch(self, what: str, index: int = 0) -> Tensor:
         """Test hook: intermediates of the last ``predict(..., _keep_hidden=True)`` as CPU fp32 tensors."""

@@ -169,6 +169,8 @@ def main():
                     help="second precision mode reported under throughput_mode (N=1 only; empty string to skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=4)
+    ap.add_argument("--decoded-gather", action="store_true",
+                    help="N > 1: also time the step that gathers greedy CTC alignments of the phoneme output instead of log-probs")
     ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the weak-scaling leg (32 x 10 s per GPU)")
     args = ap.parse_args()
 
@@ -387,6 +389,34 @@ def main():
                 "value": frames_global * world * args.steps / e_weak, "unit": "frames/s", "ms_per_step": e_weak / args.steps * 1e3,
                 "global_batch": n_global * world, "utterances_per_gpu": n_global,
                 "note": "BASELINE config 2 on every GPU (per-GPU work fixed), log-probs gathered to rank 0 the same way",
+            }
+    # N > 1, on request: SURVEY 8 f1 -- decode on every GPU and gather only the phoneme alignments (token ids, timesteps,
+    # scores) to rank 0: synchronous per step (the padded alignment length is agreed on with an all-reduce first)
+    if use_dist and args.decoded_gather:
+        est = Estimator(spec, state, device, args.precision)
+
+        def decoded_step():
+            return parallel.gather_decoded(est.greedy_decode_device(est.predict(local, tfi, True)), ["phoneme"], n_global,
+                                           device, dst=0)
+
+        for _ in range(args.warmup):
+            decoded_step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            hyps = decoded_step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        e_dec = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+        dist.all_reduce(e_dec, op=dist.ReduceOp.MAX)
+        est.close()
+        if rank == 0:
+            result["decoded_gather"] = {
+                "value": frames_global * args.steps / float(e_dec.item()), "unit": "frames/s",
+                "ms_per_step": float(e_dec.item()) / args.steps * 1e3, "outputs": ["phoneme"],
+                "hypotheses_on_rank0": len(hyps["phoneme"]),
+                "note": "greedy CTC on every GPU, one packed int32 gather of the alignments per step (no log-probs cross xGMI)",
             }
     # the single-plane 16-bit throughput mode of the same workload (error measured and bounded in tests/, not a parity
     # mode): reported beside the parity-mode headline, never as `value`

@@ -203,3 +203,56 @@ def test_bench_strong_scaling_path_two_ranks(tmp_path):
         for name in ref:
             assert g["outputs"][name].shape == ref[name].shape
             assert (g["outputs"][name] - ref[name]).abs().max().item() < 1e-4, (step, name)
+
+
+def _global_decoded(total, seed):
+    """Seeded alignments of a ``total``-utterance batch in ``Decoded`` form (three outputs, up to 20 frames)."""
+    from allophant_amd.estimator import Decoded
+
+    g = torch.Generator().manual_seed(seed)
+    n_out, frames = 3, 20
+    counts = torch.randint(0, frames + 1, (n_out, total), generator=g, dtype=torch.int32)
+    tokens = torch.randint(1, 40, (n_out, total, frames), generator=g)
+    timesteps = torch.sort(torch.randint(1, 500, (n_out, total, frames), generator=g), dim=-1).values
+    scores = -torch.rand(n_out, total, generator=g) * 100
+    return Decoded(["syllabic", "long", "phoneme"], tokens, timesteps, counts, scores)
+
+
+def _decoded_worker(rank, world, port, total, result_path):
+    from allophant_amd.estimator import Decoded
+    from allophant_amd.parallel import gather_decoded
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    full = _global_decoded(total, seed=77)
+    lo, hi = shard_bounds(total, world)[rank]
+    local = None
+    if hi > lo:
+        local = Decoded(full.names, full.tokens[:, lo:hi], full.timesteps[:, lo:hi], full.counts[:, lo:hi], full.scores[:, lo:hi])
+    got = gather_decoded(local, ["phoneme", "long"], total, torch.device("cpu"), dst=0)
+    if rank == 0:
+        torch.save(got, result_path)
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_of_decoded_alignments(tmp_path):
+    """the data-parallel path can move greedy CTC alignments instead of log-probabilities.  Ragged shards
+    (5 utterances -> 3 + 2) and an empty shard (1 utterance on 2 ranks) must reproduce the single-process hypotheses
+    bit for bit, in utterance order, for the selected outputs only."""
+    for total in (5, 1):
+        result_path = str(tmp_path / f"decoded{total}.pt")
+        mp.spawn(_decoded_worker, args=(2, _free_port(), total, result_path), nprocs=2, join=True)
+        got = torch.load(result_path, weights_only=False)
+        want = _global_decoded(total, seed=77).select(["phoneme", "long"]).hypotheses()
+        assert list(got) == ["phoneme", "long"]
+        for name in want:
+            assert len(got[name]) == total
+            for g, w in zip(got[name], want[name]):
+                assert len(g) == 1 and g[0].words == []
+                assert g[0].tokens.dtype == torch.int64 and g[0].tokens.tolist() == w[0].tokens.tolist()
+                assert g[0].timesteps.tolist() == w[0].timesteps.tolist()
+                assert g[0].score == w[0].score

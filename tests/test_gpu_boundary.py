@@ -266,3 +266,45 @@ def test_prefetcher_matches_the_plain_loop(amd):
         count += 1
     assert count == len(plain)
     est.close()
+
+
+def test_decoded_gather_over_a_one_rank_rccl_group(amd):
+    """SURVEY 8 f1 on the device: `greedy_decode_device` keeps the alignments in HBM and `parallel.gather_decoded` moves
+    them through RCCL (a one-rank group here: the box has one GPU; the two-rank logic runs under gloo in
+    tests/test_distributed_cpu.py).  The gathered hypotheses equal the oracle decoder on the same log-probabilities."""
+    import socket
+
+    import torch.distributed as dist
+
+    from allophant_amd.parallel import gather_decoded
+    from oracle import allophant_oracle as O
+
+    spec = S.multitask_spec(S.tiny_encoder(2), ["syllabic", "long"], embedding_size=16, train_phonemes=9, n_features=5,
+                            allophone_layer=True)
+    spec["shared_phones"] = 11
+    est = amd.Estimator(spec, synthetic.make_state_dict(spec, seed=8), "cuda:0")
+    tfi = synthetic.make_inventory(spec, 11, seed=8)
+    audio, lengths = synthetic.make_audio(3, 24000, seed=8, ragged=True)
+    pred = est.predict(amd.Batch(audio.cuda(), lengths, torch.zeros(3, dtype=torch.long)), tfi)
+    decoded = est.greedy_decode_device(pred)
+    assert decoded.tokens.is_cuda and decoded.names == list(pred.outputs)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+    try:
+        got = gather_decoded(decoded, ["phoneme", "syllabic"], 3, torch.device("cuda", 0), dst=0)
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert list(got) == ["phoneme", "syllabic"]
+    for name in got:
+        want = O.greedy_ctc(pred.outputs[name].cpu().transpose(0, 1).contiguous(), pred.lengths)
+        assert len(got[name]) == 3
+        for (hyp,), (tokens, timesteps, score) in zip(got[name], want):
+            assert torch.equal(hyp.tokens, tokens) and torch.equal(hyp.timesteps, timesteps), name
+            assert abs(hyp.score - float(score)) < 1e-3 * max(1.0, abs(float(score)))
+    est.close()
