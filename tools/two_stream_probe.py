@@ -36,7 +36,9 @@ state = synthetic.make_state_dict(spec, seed=0)
 tfi = synthetic.make_inventory(spec, 27, seed=0)
 dev = torch.device("cuda", 0)
 torch.cuda.init()
-audio, lengths = synthetic.make_audio(32, 160000, seed=1234)
+TOTAL = int(os.environ.get("PROBE_UTTERANCES", "32"))  # utterances of the whole batch (even)
+HALF = TOTAL // 2
+audio, lengths = synthetic.make_audio(TOTAL, 160000, seed=1234)
 
 
 def timed(fn, name):
@@ -47,13 +49,13 @@ def timed(fn, name):
     for _ in range(10):
         fn()
     torch.cuda.synchronize()
-    print(f"{prec} {name}: {(time.perf_counter() - t0) / 10 * 1e3:.3f} ms per 32 utterances", flush=True)
+    print(f"{prec} {name}: {(time.perf_counter() - t0) / 10 * 1e3:.3f} ms per {TOTAL} utterances", flush=True)
 
 
 if pattern == "full":
     est = Estimator(spec, state, dev, prec)
-    full = Batch(audio.cuda(), lengths, torch.zeros(32, dtype=torch.long))
-    timed(lambda: est.predict(full, tfi, True), "one stream, 32 x 10 s")
+    full = Batch(audio.cuda(), lengths, torch.zeros(TOTAL, dtype=torch.long))
+    timed(lambda: est.predict(full, tfi, True), f"one stream, {TOTAL} x 10 s")
     sys.exit(0)
 
 
@@ -80,7 +82,7 @@ def masked_streams(pat):
     return streams
 
 
-halves = [Batch(audio[i * 16:(i + 1) * 16].cuda(), lengths[i * 16:(i + 1) * 16], torch.zeros(16, dtype=torch.long)) for i in range(2)]
+halves = [Batch(audio[i * HALF:(i + 1) * HALF].cuda(), lengths[i * HALF:(i + 1) * HALF], torch.zeros(HALF, dtype=torch.long)) for i in range(2)]
 ests = [Estimator(spec, state, dev, prec) for _ in range(2)]
 streams = masked_streams(pattern)
 
@@ -91,9 +93,9 @@ def run_halves():
             est.predict(half, tfi, True)
 
 
-timed(run_halves, f"two streams ({pattern}, AMX_FORCE_CUS={os.environ.get('AMX_FORCE_CUS', '-')}), 2 x (16 x 10 s)")
+timed(run_halves, f"two streams ({pattern}, AMX_FORCE_CUS={os.environ.get('AMX_FORCE_CUS', '-')}), 2 x ({HALF} x 10 s)")
 # one half alone on its masked stream: what a half chip does with a half batch
 def run_one():
     with torch.cuda.stream(streams[0]):
         ests[0].predict(halves[0], tfi, True)
-timed(run_one, f"   one masked stream alone, 16 x 10 s")
+timed(run_one, f"   one masked stream alone, {HALF} x 10 s")
