@@ -151,10 +151,12 @@ __global__ __launch_bounds__(512, 2) void posconv_window_kernel(const T* __restr
             const int c = ni * 16 + 4 * (lane >> 4);
             const float4 b4 = *(const float4*)(bias + g * PC_CG + c);
             float4 r4 = *(const float4*)(row + c);
-            r4.x += gelu_fast(acc[ni][mi][0] + b4.x);
-            r4.y += gelu_fast(acc[ni][mi][1] + b4.y);
-            r4.z += gelu_fast(acc[ni][mi][2] + b4.z);
-            r4.w += gelu_fast(acc[ni][mi][3] + b4.w);
+            const f32x2 g01 = gelu_fast2(f32x2{acc[ni][mi][0] + b4.x, acc[ni][mi][1] + b4.y});
+            const f32x2 g23 = gelu_fast2(f32x2{acc[ni][mi][2] + b4.z, acc[ni][mi][3] + b4.w});
+            r4.x += g01[0];
+            r4.y += g01[1];
+            r4.z += g23[0];
+            r4.w += g23[1];
             *(float4*)(row + c) = r4;
         }
     }

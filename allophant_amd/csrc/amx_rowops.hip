@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ au
 #pragma unroll
                 for (int i = 0; i < CP; ++i) {
                     const f32x2 v = (acc[u][i] - m2) * r2 * g2[i] + be2[i];
-                    f32x2 y = {gelu_fast(v[0]), gelu_fast(v[1])};
+                    f32x2 y = gelu_fast2(v);
                     // one register pair for y: its 16-bit image and the residual are taken from the same value (see split16)
                     asm volatile("" : "+v"(y));
                     hi[i] = __builtin_convertvector(y, V2);
@@ -322,7 +322,10 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
                 y.y = (v[i].y - mu) * rs * gg.y + bb.y;
                 y.z = (v[i].z - mu) * rs * gg.z + bb.z;
                 y.w = (v[i].w - mu) * rs * gg.w + bb.w;
-                if (act) { y.x = gelu_fast(y.x); y.y = gelu_fast(y.y); y.z = gelu_fast(y.z); y.w = gelu_fast(y.w); }
+                if (act) {
+                    const f32x2 g01 = gelu_fast2(f32x2{y.x, y.y}), g23 = gelu_fast2(f32x2{y.z, y.w});
+                    y.x = g01[0]; y.y = g01[1]; y.z = g23[0]; y.w = g23[1];
+                }
                 v[i] = y;
             }
         }
