@@ -60,6 +60,20 @@ __device__ __forceinline__ void split16(float x, T& hi, T& lo) {
     }
 }
 
+// the same for two values at once: packed converts (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32) and one v_pk_add_f32 for the
+// residuals; `y` and `hi` are pinned to one register (pair) each like in split16
+template <typename T, int NT>
+__device__ __forceinline__ void split16x2(f32x2 y, typename Vec2<T>::type& hi, typename Vec2<T>::type& lo) {
+    typedef typename Vec2<T>::type V2;
+    if (NT > 1) asm volatile("" : "+v"(y));
+    hi = __builtin_convertvector(y, V2);
+    if (NT > 1) {
+        asm volatile("" : "+v"(hi));
+        const f32x2 back = {(float)hi[0], (float)hi[1]};
+        lo = __builtin_convertvector(y - back, V2);
+    }
+}
+
 // exact (erf) GELU as  gelu(x) = max(x, 0) - |x| * 2^-(|x| Q(|x|) + 1),  where  |x| Q(|x|) = -log2(erfc(|x| / sqrt 2))  and Q
 // is a degree-6 minimax fit on [0, 5.7] (weighted by the sensitivity |x|^2 erfc; beyond 5.7 the correction is < 1e-8 and
 // |x| is clamped).  One quarter-rate instruction (v_exp_f32) and 8 FMAs that pack two values per v_pk_fma_f32: the
