@@ -40,6 +40,7 @@ from allophant_amd import spec as S, synthetic  # noqa: E402
 
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/f16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 HBM_PEAK_GBS = 8000.0
+MEASURED_STORE_CEILING_GBS = 5100.0  # best pure-store rate of tools/hbm_bw_probe.hip on an MI355X (profiles/r02_hbm_bw.log)
 TRAFFIC_FILES = ("r02_traffic.json", "r01_gemm_traffic.json")  # newest first; written by tools/collect_profiles.py
 
 
@@ -297,6 +298,10 @@ def main():
                     "bound": "hbm", "algorithmic_bytes": w["conv0_bytes"], "ms": conv0_ms, "achieved": conv0_gbs,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": conv0_gbs / HBM_PEAK_GBS if conv0_gbs else None,
                     "traffic": traffic.get("conv0_hbm_bytes_per_launch"),
+                    # 99 % of this kernel's bytes are stores; a pure 16-byte store kernel reaches 3.9-5.1 TB/s on this part
+                    # (tools/hbm_bw_probe.hip, profiles/r02_hbm_bw.log; reads 6.3 TB/s), so the store ceiling is the nearer bound
+                    "store_ceiling": MEASURED_STORE_CEILING_GBS,
+                    "frac_of_store_ceiling": conv0_gbs / MEASURED_STORE_CEILING_GBS if conv0_gbs else None,
                 },
                 "conv1_5": {
                     "kernel": "gemm_ln_kernel<T16, planes>: 128x512 row-complete implicit GEMM + LayerNorm + GELU",
