@@ -131,8 +131,28 @@ __global__ __launch_bounds__(WAVES * 64, AMX_ATTN_OCC) void attn_kernel(const At
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
+#ifdef AMX_ATTN_STAMP
+    // developer diagnostic (tools/attn_bench.hip): cycles per phase of a key tile, summed in scalar registers
+    unsigned long long st_s = 0, st_max = 0, st_exp = 0, st_pv = 0, st_wait = 0, st_bar = 0;
+    auto stamp = []() -> unsigned long long {
+        unsigned long long t;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+        return t;
+    };
+    unsigned long long st_rt0;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt0)::"memory");
+    const unsigned long long st_begin = stamp();
+#define ATTN_STAMP(var, prev) { const unsigned long long now_ = stamp(); var += now_ - prev; prev = now_; }
+#else
+#define ATTN_STAMP(var, prev)
+#endif
     auto tile = [&](int kt, auto stc) {
         constexpr int ST = decltype(stc)::value;
+#ifdef AMX_ATTN_STAMP
+        unsigned long long st_prev = stamp();
+#endif
         if (kt + 1 < nkt) stage(kt + 1, ST ^ 1);
         const unsigned char* sb = smem + ST * STAGE;
 
@@ -145,15 +165,26 @@ __global__ __launch_bounds__(WAVES * 64, AMX_ATTN_OCC) void attn_kernel(const At
             for (int r = 0; r < 16; ++r) X[c][r] = neg_m;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
+#ifdef AMX_ATTN_ABL_NOLDS  // developer ablation (wrong results): one K fragment read per tile instead of 16
+                const V8 kf = *(const V8*)(sb + kaddr0);
+                if (NT > 1) {
+                    const V8 kl = *(const V8*)(sb + 2 * TILE + kaddr0);
+#else
                 const V8 kf = *(const V8*)(sb + c * 4096 + (kaddr0 ^ (ks << 5)));
                 if (NT > 1) {
                     const V8 kl = *(const V8*)(sb + 2 * TILE + c * 4096 + (kaddr0 ^ (ks << 5)));
+#endif
+#ifndef AMX_ATTN_ABL_NOCROSS  // developer ablation (results lose the lo planes): a third of the MFMAs, same loads
                     X[c] = mfma32(kl, qf[0][ks], X[c]);
                     X[c] = mfma32(kf, qf[NT - 1][ks], X[c]);
+#else
+                    asm volatile("" ::"v"(kl));
+#endif
                 }
                 X[c] = mfma32(kf, qf[0][ks], X[c]);
             }
         }
+        ATTN_STAMP(st_s, st_prev)
         const int kb = kt * KT;
         if (kb + KT > klen) {  // only the last tile holds masked keys (wave-uniform branch)
             const int rem = klen - kb - 4 * hh;  // keys of this lane's rows left in the utterance
@@ -196,17 +227,23 @@ __global__ __launch_bounds__(WAVES * 64, AMX_ATTN_OCC) void attn_kernel(const At
 #pragma unroll
                 for (int r = 0; r < 16; ++r) X[c][r] -= d;
         }
+        ATTN_STAMP(st_max, st_prev)
         f32x2 ps = {0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < NC; ++c)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
+#ifdef AMX_ATTN_ABL_NOEXP  // developer ablation (wrong results): no transcendental
+                const f32x2 e = {X[c][r] * X[c][r], X[c][r + 1] * X[c][r + 1]};
+#else
                 const f32x2 e = {__builtin_amdgcn_exp2f(X[c][r]), __builtin_amdgcn_exp2f(X[c][r + 1])};
+#endif
                 X[c][r] = e[0];
                 X[c][r + 1] = e[1];
                 ps += e;  // v_pk_add_f32
             }
         l_run += ps[0] + ps[1];
+        ATTN_STAMP(st_exp, st_prev)
 
         // ---- O^T += V^T . P : P's accumulator registers are the B operand ----
 #pragma unroll
@@ -227,7 +264,11 @@ __global__ __launch_bounds__(WAVES * 64, AMX_ATTN_OCC) void attn_kernel(const At
                         pl_.h[j] = __builtin_convertvector(x - back, V2);
                     }
                 }
+#ifdef AMX_ATTN_ABL_NOLDS
+                const int koff = 0;
+#else
                 const int koff = c * 4096 + s2 * 2048;  // key rows 32c + 16s2 (+ 8g)
+#endif
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
                     union { s16x4 h[2]; V8 v; } vf, vl;
@@ -236,8 +277,12 @@ __global__ __launch_bounds__(WAVES * 64, AMX_ATTN_OCC) void attn_kernel(const At
                     if (NT > 1) {
                         vl.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(sb + 2 * TILE + koff + vaddr[dt]));
                         vl.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(sb + 2 * TILE + koff + 1024 + vaddr[dt]));
+#ifndef AMX_ATTN_ABL_NOCROSS
                         O[dt] = mfma32(vl.v, ph.v, O[dt]);
                         O[dt] = mfma32(vf.v, pl_.v, O[dt]);
+#else
+                        asm volatile("" ::"v"(vl.v), "v"(pl_.v));
+#endif
                     }
                     O[dt] = mfma32(vf.v, ph.v, O[dt]);
                 }
@@ -248,8 +293,11 @@ __global__ __launch_bounds__(WAVES * 64, AMX_ATTN_OCC) void attn_kernel(const At
         // before the barrier retired those reads").  Without the lgkmcnt(0) hipcc leaves the V reads of the last P.V group
         // in flight across the barrier: one 32-query block in ~1000 launches came out with a few keys of the wrong tile
         // (4 x 60 s batches, tools/stress_repro.py).
+        ATTN_STAMP(st_pv, st_prev)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        ATTN_STAMP(st_wait, st_prev)
         __builtin_amdgcn_s_barrier();
+        ATTN_STAMP(st_bar, st_prev)
     };
 
     for (int kt = 0; kt < nkt; kt += 2) {
@@ -257,6 +305,9 @@ __global__ __launch_bounds__(WAVES * 64, AMX_ATTN_OCC) void attn_kernel(const At
         if (kt + 1 < nkt) tile(kt + 1, std::integral_constant<int, 1>{});
     }
 
+#ifdef AMX_ATTN_STAMP
+    const unsigned long long st_loop_end = stamp();
+#endif
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
     if (query < p.T) {
@@ -278,11 +329,26 @@ __global__ __launch_bounds__(WAVES * 64, AMX_ATTN_OCC) void attn_kernel(const At
                 if (NT > 1) *(V4*)(dst + p.out_plane + d0) = lv;
             }
     }
+#ifdef AMX_ATTN_STAMP
+    if (p.stamps && lane == 0) {
+        const unsigned long long st_end = stamp();
+        unsigned long long st_rt1;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt1)::"memory");
+        unsigned long long* o = p.stamps + ((int64_t)blockIdx.x * WAVES + wave) * 12;
+        o[0] = st_s; o[1] = st_max; o[2] = st_exp; o[3] = st_pv; o[4] = st_wait; o[5] = st_bar;
+        o[6] = st_loop_end - st_begin; o[7] = st_end - st_loop_end; o[8] = (unsigned long long)nkt; o[9] = 1;
+        o[10] = st_rt0; o[11] = st_rt1;  // 100 MHz wall clock at start / end of the wave
+    }
+#endif
 }
 
 template <typename T, int NT, int WAVES, int KT>
 void launch_attn(const AttnParams& p, hipStream_t stream) {
+#ifdef AMX_ATTN_ABL_ONE_WG  // developer ablation: pad the LDS request so that only one workgroup fits a CU
+    constexpr int lds = 100 * 1024;
+#else
     constexpr int lds = 2 * NT * 2 * KT * 128;
+#endif
     static OncePerDevice attr;
     if (attr.first())
         (void)hipFuncSetAttribute((const void*)attn_kernel<T, NT, WAVES, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -226,6 +226,7 @@ struct AttnParams {
     int64_t out_plane;
     const int* frame_len;  // [N] valid keys per utterance
     int N, H, T, Tp, dh;
+    unsigned long long* stamps;  // developer diagnostic (-DAMX_ATTN_STAMP builds of tools/attn_bench.hip), else null
 };
 void launch_attention(int prec, const AttnParams& p, hipStream_t stream);
 

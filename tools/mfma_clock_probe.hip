@@ -44,6 +44,43 @@ __global__ __launch_bounds__(512) void mfma_loop(float* out, unsigned long long*
     }
 }
 
+// dependent chains: every MFMA accumulates into one of NACC accumulators in turn (NACC = 1: each MFMA waits for its predecessor;
+// the attention kernel chains 3-12 MFMAs on one accumulator)
+template <int NACC>
+__global__ __launch_bounds__(1024) void mfma_chain32(float* out, int iters) {
+    f16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(0.001f * (threadIdx.x + i)); b[i] = (_Float16)(0.002f * (threadIdx.x - i)); }
+    f32x16 acc[NACC];
+    for (int i = 0; i < NACC; ++i)
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[i % NACC]) : "v"(a), "v"(b));
+    }
+    float sink = 0.f;
+    for (int i = 0; i < NACC; ++i) sink += acc[i][0];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = sink;
+}
+
+template <int NACC>
+static void run_chain(float* out, int threads) {
+    const int iters = 20000;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    float ms = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(mfma_chain32<NACC>, dim3(256), dim3(threads), 0, 0, out, iters);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+    }
+    const double flop = 8.0 * iters * 32.0 * 32 * 16 * 2 * (threads / 64) * 256;
+    printf("32x32x16 chains on %d accumulator(s), %d wave(s) per SIMD: %.0f TFLOP/s (%.1f %% of 2500)\n", NACC, threads / 256, flop / ms / 1e9,
+           flop / ms / 1e9 / 25.0);
+}
+
 int main() {
     float* out;
     unsigned long long* st;
@@ -75,6 +112,13 @@ int main() {
                            cyc / 256 / mfmas);
             }
         }
+    }
+    float* out2;
+    hipMalloc(&out2, 256 * 1024 * 4);
+    for (int threads : {256, 512, 1024}) {
+        run_chain<1>(out2, threads);
+        run_chain<2>(out2, threads);
+        run_chain<8>(out2, threads);
     }
     return 0;
 }
