@@ -40,6 +40,7 @@ from allophant_amd import spec as S, synthetic  # noqa: E402
 
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/f16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 HBM_PEAK_GBS = 8000.0
+MEASURED_MFMA_CEILING_TFLOPS = 2100.0  # 16x16x32 f16, two waves per SIMD (profiles/r02_mfma_only_ceiling.log)
 MEASURED_STORE_CEILING_GBS = 5100.0  # best pure-store rate of tools/hbm_bw_probe.hip on an MI355X (profiles/r02_hbm_bw.log)
 TRAFFIC_FILES = ("r02_traffic.json", "r01_gemm_traffic.json")  # newest first; written by tools/collect_profiles.py
 
@@ -291,6 +292,10 @@ def main():
             "launches_per_step": gemm_launches // max(1, steps),
             "mfma_issue_factor": issue,
             "issued_frac": issue * achieved / MFMA_PEAK_TFLOPS if achieved else None,
+            # what a loop of nothing but independent MFMAs sustains on an MI355X (tools/mfma_clock_probe.hip,
+            # profiles/r02_mfma_only_ceiling.log: the clock falls to ~2.0 GHz under matrix load), for scale beside `peak`
+            "measured_mfma_only_ceiling": MEASURED_MFMA_CEILING_TFLOPS,
+            "issued_frac_of_measured_ceiling": issue * achieved / MEASURED_MFMA_CEILING_TFLOPS if achieved else None,
             # the conv feature extractor (north-star: HBM fraction of the conv stage with rocprof evidence)
             "conv_stage": {
                 "conv0": {
