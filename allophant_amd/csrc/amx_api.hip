@@ -117,6 +117,7 @@ struct amx_handle_s {
     static constexpr int PIN_SLOTS = 4;
     int64_t* h_lengths_pinned[PIN_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     int* h_frames_pinned[PIN_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    int* h_rowoff_pinned[PIN_SLOTS] = {nullptr, nullptr, nullptr, nullptr};  // packed-row offsets of the utterances (N + 1)
     hipEvent_t pin_event[PIN_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     bool pin_busy[PIN_SLOTS] = {false, false, false, false};
     int pin_next = 0;
@@ -129,6 +130,7 @@ struct amx_handle_s {
     hipStream_t timing_stream = nullptr;
     // last forward geometry
     int last_N = 0;
+    bool qkv_dirty = false;
     int64_t last_L = 0, last_T = 0;
     bool last_keep = false;
 };
@@ -601,6 +603,7 @@ extern "C" int amx_destroy(amx_handle h) {
     for (int i = 0; i < amx_handle_s::PIN_SLOTS; ++i) {
         if (h->h_lengths_pinned[i]) (void)hipHostFree(h->h_lengths_pinned[i]);
         if (h->h_frames_pinned[i]) (void)hipHostFree(h->h_frames_pinned[i]);
+        if (h->h_rowoff_pinned[i]) (void)hipHostFree(h->h_rowoff_pinned[i]);
         if (h->pin_event[i]) (void)hipEventDestroy(h->pin_event[i]);
     }
     for (auto& sp : h->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
@@ -885,9 +888,14 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     if (h->pinned_cap < N) {
         HIPCHK(h, hipStreamSynchronize(s));
         for (int i = 0; i < amx_handle_s::PIN_SLOTS; ++i) {
-            if (h->h_lengths_pinned[i]) { (void)hipHostFree(h->h_lengths_pinned[i]); (void)hipHostFree(h->h_frames_pinned[i]); }
+            if (h->h_lengths_pinned[i]) {
+                (void)hipHostFree(h->h_lengths_pinned[i]);
+                (void)hipHostFree(h->h_frames_pinned[i]);
+                (void)hipHostFree(h->h_rowoff_pinned[i]);
+            }
             HIPCHK(h, hipHostMalloc((void**)&h->h_lengths_pinned[i], (size_t)N * 8));
             HIPCHK(h, hipHostMalloc((void**)&h->h_frames_pinned[i], (size_t)N * 4));
+            HIPCHK(h, hipHostMalloc((void**)&h->h_rowoff_pinned[i], (size_t)(N + 1) * 4));
             if (!h->pin_event[i]) HIPCHK(h, hipEventCreateWithFlags(&h->pin_event[i], hipEventDisableTiming));
             h->pin_busy[i] = false;
         }
@@ -898,13 +906,18 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     if (h->pin_busy[slot]) HIPCHK(h, hipEventSynchronize(h->pin_event[slot]));  // its copies ran PIN_SLOTS calls ago
     int64_t* pin_len = h->h_lengths_pinned[slot];
     int* pin_frames = h->h_frames_pinned[slot];
+    int* pin_rowoff = h->h_rowoff_pinned[slot];
+    int64_t Mp = 0;  // valid frames of the batch = rows of the packed layout
     for (int n = 0; n < N; ++n) {
         pin_len[n] = lengths[n];
         int64_t f = frames_of(c, lengths[n]);
         if (f < 1) return fail(h, AMX_EINVAL, "utterance shorter than the receptive field of the feature extractor");
         pin_frames[n] = (int)f;
+        pin_rowoff[n] = (int)Mp;
+        Mp += f;
         if (out_lengths) out_lengths[n] = f;
     }
+    pin_rowoff[N] = (int)Mp;
 
     // ---- workspace ----
     void *d_len, *d_frames, *d_partial, *d_stats, *actA, *actB, *preln, *hbuf, *xp, *hg, *qb, *kb, *vtb, *ao, *ff, *hfin, *logits;
@@ -925,6 +938,8 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     };
     WS("len", (size_t)N * 8, d_len);
     WS("frames", (size_t)N * 4, d_frames);
+    void* d_rowoff;
+    WS("rowoff", (size_t)(N + 1) * 4, d_rowoff);
     WS("partial", (size_t)N * 64 * 3 * 8, d_partial);
     WS("stats", (size_t)N * 2 * 4, d_stats);
     WS("actA", (size_t)rows1 * C * 2 * NT, actA);
@@ -941,11 +956,30 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     WS("ff", (size_t)M * F * 2 * NT, ff);
     WS("hfin", (size_t)M * D * 4, hfin);
     WS("logits", (size_t)M * h->ld_logits * 4, logits);
+    // Packed rows: a ragged batch runs its encoder layers on the valid frames only (rows of utterance n at row_off[n], all
+    // utterances back to back): every kernel of a layer is row-wise except the attention, which takes the offsets.  The
+    // results on valid frames are the same bits as in the padded layout (each row's arithmetic does not depend on its
+    // position).  Used when at least a tenth of the padded rows are padding and no caller needs per-layer hidden states in
+    // the padded layout; AMX_FLAG_NO_PACK / AMX_NO_PACKED_ROWS=1 keep the padded layout.
+    static const bool no_pack_env = getenv("AMX_NO_PACKED_ROWS") && atoi(getenv("AMX_NO_PACKED_ROWS")) != 0;
+    bool any_hidden = keep;
+    for (int l = 0; l < c.layers; ++l) any_hidden = any_hidden || h->need_hidden[l];
+    const int TpTot = round_up((int)Mp, 64) + 64;  // rows per head of the packed Q / K / V planes
+    const bool packed = !no_pack_env && !(flags & AMX_FLAG_NO_PACK) && !any_hidden && D % 4 == 0 && Mp * 10 <= M * 9 &&
+                        (int64_t)TpTot <= (int64_t)N * Tp;
     // K/V/Q padding rows [T, Tp) must stay finite: re-zero when the geometry changes
-    if (h->last_N != N || h->last_T != T) {
+    if (!packed && (h->last_N != N || h->last_T != T || h->qkv_dirty)) {
         HIPCHK(h, hipMemsetAsync(qb, 0, qkv_bytes, s));
         HIPCHK(h, hipMemsetAsync(kb, 0, qkv_bytes, s));
         HIPCHK(h, hipMemsetAsync(vtb, 0, qkv_bytes, s));
+    }
+    void* hpk = nullptr;
+    if (packed) {
+        WS("h_packed", (size_t)Mp * D * 4, hpk);
+        // rows [Mp, TpTot) of every head are read (never used) by the last key tile and query block: keep them finite
+        const size_t row_b = 64 * 2, tail = (size_t)(TpTot - Mp) * row_b, pitch = (size_t)TpTot * row_b;
+        for (void* buf : {qb, kb, vtb})  // the planes lie back to back: NT * H blocks of TpTot rows
+            HIPCHK(h, hipMemset2DAsync((char*)buf + (size_t)Mp * row_b, pitch, 0, tail, (size_t)NT * H, s));
     }
     const float* d_audio = audio;
     float* d_out = out;
@@ -976,6 +1010,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
 
     HIPCHK(h, hipMemcpyAsync(d_len, pin_len, (size_t)N * 8, hipMemcpyHostToDevice, s));
     HIPCHK(h, hipMemcpyAsync(d_frames, pin_frames, (size_t)N * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(d_rowoff, pin_rowoff, (size_t)(N + 1) * 4, hipMemcpyHostToDevice, s));
     HIPCHK(h, hipEventRecord(h->pin_event[slot], s));
     h->pin_busy[slot] = true;
 
@@ -1064,63 +1099,78 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         }
     }
     // ---- transformer encoder (pre-LN) ----
-    const int64_t xp_plane = M * D;
+    void* const hpad = hbuf;     // the padded residual stream [N * T, D]
+    const int64_t Mpad = M;
+    if (packed) {
+        { Timed t_(h, AMX_KC_OTHER); launch_pack_rows((const float*)hpad, (float*)hpk, (const int*)d_rowoff, (const int*)d_frames, N, T, D, false, s); }
+        hbuf = hpk;
+    }
+    const int64_t Mrows = packed ? Mp : Mpad;  // rows the layers work on
+    const int64_t xp_plane = Mrows * D;
+    const int64_t qk_plane = packed ? (int64_t)H * TpTot * 64 : (int64_t)N * H * Tp * 64;
     for (int l = 0; l < c.layers; ++l) {
         const Layer& ly = h->layers[l];
         if (saved[l]) HIPCHK(h, hipMemcpyAsync(saved[l], hbuf, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s));
-        { Timed t_(h, AMX_KC_ROWNORM); launch_rownorm(prec, (const float*)hbuf, D, M, D, ly.ln1_g, ly.ln1_b, 0, nullptr, nullptr, c.eps, 0.f, xp, xp_plane, D,
+        { Timed t_(h, AMX_KC_ROWNORM); launch_rownorm(prec, (const float*)hbuf, D, Mrows, D, ly.ln1_g, ly.ln1_b, 0, nullptr, nullptr, c.eps, 0.f, xp, xp_plane, D,
                        nullptr, 0, s); }
         {
             GemmParams g{};
-            g.A = xp; g.a_plane = xp_plane; g.lda = D; g.rows_per_batch = M;
+            g.A = xp; g.a_plane = xp_plane; g.lda = D; g.rows_per_batch = Mrows;
             g.W = ly.wqkv; g.w_plane = (int64_t)3 * D * D; g.ldw = D;
-            g.M = (int)M; g.N = 3 * D; g.K = D;
+            g.M = (int)Mrows; g.N = 3 * D; g.K = D;
             g.scale = 1.f; g.bias = ly.bqkv;
             g.mode = 1; g.q = qb; g.k = kb; g.v = vtb;
-            g.qk_plane = (int64_t)N * H * Tp * 64;
-            g.T = T; g.Tp = Tp; g.H = H; g.dh = 64;
+            g.qk_plane = qk_plane;
+            // packed rows: one "utterance" of Mp rows, so the scatter writes row m of head hh to [hh][m][:]
+            g.T = packed ? (int)std::max<int64_t>(Mp, 8) : T; g.Tp = packed ? TpTot : Tp; g.H = H; g.dh = 64;
             { Timed t_(h, gemm_class(prec, g)); run_gemm(prec, g, s); }
         }
         {
             AttnParams a{};
             a.q = qb; a.k = kb; a.v = vtb;
-            a.qk_plane = (int64_t)N * H * Tp * 64;
+            a.qk_plane = qk_plane;
             a.out = ao; a.out_plane = xp_plane;
             a.frame_len = (const int*)d_frames;
-            a.N = N; a.H = H; a.T = T; a.Tp = Tp; a.dh = 64;
+            a.N = N; a.H = H; a.T = T; a.Tp = packed ? TpTot : Tp; a.dh = 64;
+            a.row_off = packed ? (const int*)d_rowoff : nullptr;
             { Timed t_(h, AMX_KC_ATTENTION); launch_attention(prec, a, s); }
         }
         {
             GemmParams g{};
-            g.A = ao; g.a_plane = xp_plane; g.lda = D; g.rows_per_batch = M;
+            g.A = ao; g.a_plane = xp_plane; g.lda = D; g.rows_per_batch = Mrows;
             g.W = ly.wo; g.w_plane = (int64_t)D * D; g.ldw = D;
-            g.M = (int)M; g.N = D; g.K = D;
+            g.M = (int)Mrows; g.N = D; g.K = D;
             g.scale = 1.f; g.bias = ly.bo;
             g.residual = (const float*)hbuf; g.ldr = D; g.out_f32 = (float*)hbuf; g.ldo = D;
             { Timed t_(h, gemm_class(prec, g)); run_gemm(prec, g, s); }
         }
-        { Timed t_(h, AMX_KC_ROWNORM); launch_rownorm(prec, (const float*)hbuf, D, M, D, ly.ln2_g, ly.ln2_b, 0, nullptr, nullptr, c.eps, 0.f, xp, xp_plane, D,
+        { Timed t_(h, AMX_KC_ROWNORM); launch_rownorm(prec, (const float*)hbuf, D, Mrows, D, ly.ln2_g, ly.ln2_b, 0, nullptr, nullptr, c.eps, 0.f, xp, xp_plane, D,
                        nullptr, 0, s); }
         {
             GemmParams g{};
-            g.A = xp; g.a_plane = xp_plane; g.lda = D; g.rows_per_batch = M;
+            g.A = xp; g.a_plane = xp_plane; g.lda = D; g.rows_per_batch = Mrows;
             g.W = ly.w1; g.w_plane = (int64_t)F * D; g.ldw = D;
-            g.M = (int)M; g.N = F; g.K = D;
+            g.M = (int)Mrows; g.N = F; g.K = D;
             g.scale = 1.f; g.bias = ly.b1; g.act = 1;
-            g.out_p = ff; g.out_plane = M * F; g.ldp = F;
+            g.out_p = ff; g.out_plane = Mrows * F; g.ldp = F;
             { Timed t_(h, gemm_class(prec, g)); run_gemm(prec, g, s); }
         }
         {
             GemmParams g{};
-            g.A = ff; g.a_plane = M * F; g.lda = F; g.rows_per_batch = M;
+            g.A = ff; g.a_plane = Mrows * F; g.lda = F; g.rows_per_batch = Mrows;
             g.W = ly.w2; g.w_plane = (int64_t)D * F; g.ldw = F;
-            g.M = (int)M; g.N = D; g.K = F;
+            g.M = (int)Mrows; g.N = D; g.K = F;
             g.scale = 1.f; g.bias = ly.b2;
             g.residual = (const float*)hbuf; g.ldr = D; g.out_f32 = (float*)hbuf; g.ldo = D;
             { Timed t_(h, gemm_class(prec, g)); run_gemm(prec, g, s); }
         }
     }
-    { Timed t_(h, AMX_KC_ROWNORM); launch_rownorm(prec, (const float*)hbuf, D, M, D, h->fln_g, h->fln_b, 0, nullptr, nullptr, c.eps, 0.f, xp, xp_plane, D,
+    if (packed) {
+        // back to the padded layout for the final LayerNorm and the projection (padded frames keep their pre-encoder rows)
+        { Timed t_(h, AMX_KC_OTHER); launch_pack_rows((const float*)hpad, (float*)hpk, (const int*)d_rowoff, (const int*)d_frames, N, T, D, true, s); }
+        hbuf = hpad;
+    }
+    { Timed t_(h, AMX_KC_ROWNORM); launch_rownorm(prec, (const float*)hbuf, D, M, D, h->fln_g, h->fln_b, 0, nullptr, nullptr, c.eps, 0.f, xp, M * D, D,
                    (float*)hfin, D, s); }
 
     // ---- hierarchical projection ----
@@ -1148,7 +1198,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     const bool blanks = c.dependency_blanks != 0;
     for (auto& st : h->steps) {
         const void* A = xp;
-        int64_t a_plane = xp_plane, lda = D;
+        int64_t a_plane = M * D, lda = D;
         if (!st.direct_output) {
             for (size_t i = 0; i < st.parts.size(); ++i) {
                 int dep = st.part_dep[i];
@@ -1227,6 +1277,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         HIPCHK(h, hipStreamSynchronize(s));
     }
     h->last_N = N; h->last_L = L; h->last_T = T; h->last_keep = keep;
+    h->qkv_dirty = packed;  // a packed call leaves other rows in the Q / K / V planes: the next padded call re-zeroes them
 #undef WS
     return AMX_OK;
 }

@@ -72,18 +72,23 @@ __global__ __launch_bounds__(WAVES * 64, AMX_ATTN_OCC) void attn_kernel(const At
     int klen = p.frame_len[n];
     klen = klen < 1 ? 1 : (klen > p.T ? p.T : klen);
     const int nkt = (klen + KT - 1) / KT;
+    // packed rows: the utterance starts at row row_off[n] of every head's [Tp, 64] block; query blocks past its end do
+    // not exist (in the padded layout they are computed like the reference computes them: the rows feed later kernels)
+    const bool packed = p.row_off != nullptr;
+    const int roff = packed ? p.row_off[n] : 0;
+    if (packed && qblock * QB >= klen) return;
+    const int64_t first = packed ? ((int64_t)h * p.Tp + roff) * DH : (int64_t)nh * p.Tp * DH;  // element offset of row 0
+    const int q_rows = packed ? p.Tp - roff : p.Tp;  // rows that may be read from `first` on
 
-    const T* Qb = (const T*)p.q + (int64_t)nh * p.Tp * DH;
-    const __amdgpu_buffer_rsrc_t k_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.k + (int64_t)nh * p.Tp * DH), 0, -1, 0x00020000);
-    const __amdgpu_buffer_rsrc_t v_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.v + (int64_t)nh * p.Tp * DH), 0, -1, 0x00020000);
+    const T* Qb = (const T*)p.q + first;
+    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.k + first), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.v + first), 0, -1, 0x00020000);
     const uint32_t plane_b = (uint32_t)(p.qk_plane * 2);
 
     // Q fragments (B operand): lane (query, hh) holds Q[query][16ks + 8hh + j]
     V8 qf[NT][4];
     {
-        const int qr = query < p.Tp ? query : p.Tp - 1;
+        const int qr = query < q_rows ? query : q_rows - 1;
 #pragma unroll
         for (int pl = 0; pl < NT; ++pl)
 #pragma unroll
@@ -310,8 +315,8 @@ __global__ __launch_bounds__(WAVES * 64, AMX_ATTN_OCC) void attn_kernel(const At
 #endif
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
-    if (query < p.T) {
-        T* dst = (T*)p.out + ((int64_t)n * p.T + query) * (p.H * DH) + h * DH;
+    if (query < (packed ? klen : p.T)) {
+        T* dst = (T*)p.out + ((packed ? (int64_t)roff : (int64_t)n * p.T) + query) * (p.H * DH) + h * DH;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll

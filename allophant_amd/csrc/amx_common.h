@@ -226,6 +226,10 @@ struct AttnParams {
     int64_t out_plane;
     const int* frame_len;  // [N] valid keys per utterance
     int N, H, T, Tp, dh;
+    // packed rows (null: padded layout as described above).  With row_off the utterances lie back to back: Q / K / V are
+    // [H, Tp, dh] planes in which utterance n owns rows row_off[n] .. row_off[n] + frame_len[n] (Tp = rows per head, at
+    // least 64 finite rows beyond the last utterance), `out` is [sum(frame_len), D] and only valid queries are computed
+    const int* row_off;
     unsigned long long* stamps;  // developer diagnostic (-DAMX_ATTN_STAMP builds of tools/attn_bench.hip), else null
 };
 void launch_attention(int prec, const AttnParams& p, hipStream_t stream);
@@ -240,6 +244,10 @@ void launch_conv0(int prec, const float* audio, const int64_t* lengths, const fl
                   int C, int k, int stride, const float* w /*[C,k]*/, const float* b, const float* gamma,
                   const float* beta, float eps, int do_normalize, void* out, int64_t out_plane, hipStream_t s);
 // rows of width D: [LN1 -> GELU] (if gamma1) then [LN2] (if gamma2); outputs planes and/or f32
+// rows of the padded [N, T, D] fp32 matrix <-> rows of the packed [sum(frame_len), D] matrix (utterance n at row_off[n]);
+// only rows t < frame_len[n] move
+void launch_pack_rows(const float* padded, float* packed, const int* row_off, const int* frame_len, int N, int T, int D, bool unpack,
+                      hipStream_t s);
 void launch_rownorm(int prec, const float* x, int64_t ldx, int64_t M, int D, const float* gamma1, const float* beta1,
                     int gelu, const float* gamma2, const float* beta2, float eps1, float eps2, void* out_p,
                     int64_t out_plane, int64_t ldp, float* out_f32, int64_t ldo, hipStream_t s);

@@ -929,4 +929,27 @@ void launch_scale_copy(const float* src, float* dst, int64_t n, float scale, hip
     hipLaunchKernelGGL(scale_copy_kernel, dim3(grid_for(n)), dim3(256), 0, s, src, dst, n, scale);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// packed rows: the encoder layers of a ragged batch run on the valid frames only
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+template <bool UNPACK>
+__global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, const int* __restrict__ row_off,
+                                                        const int* __restrict__ frame_len, int T, int D) {
+    const int n = blockIdx.y, t = blockIdx.x;
+    if (t >= frame_len[n]) return;
+    const int64_t padded_row = (int64_t)n * T + t, packed_row = (int64_t)row_off[n] + t;
+    const float4* s4 = (const float4*)(src + (UNPACK ? packed_row : padded_row) * D);
+    float4* d4 = (float4*)(dst + (UNPACK ? padded_row : packed_row) * D);
+    for (int c = threadIdx.x; c < D / 4; c += 256) d4[c] = s4[c];
+}
+}  // namespace
+
+void launch_pack_rows(const float* padded, float* packed, const int* row_off, const int* frame_len, int N, int T, int D, bool unpack,
+                      hipStream_t s) {
+    dim3 grid(T, N);
+    if (unpack) hipLaunchKernelGGL(pack_rows_kernel<true>, grid, dim3(256), 0, s, packed, const_cast<float*>(padded), row_off, frame_len, T, D);
+    else hipLaunchKernelGGL(pack_rows_kernel<false>, grid, dim3(256), 0, s, padded, packed, row_off, frame_len, T, D);
+}
+
 }  // namespace amx

@@ -266,8 +266,9 @@ class Estimator:
         self._inventory = tfi_cpu
 
     def predict(self, batch: Batch, target_feature_indices: Optional[Tensor] = None, log_probabilities: bool = True,
-                _keep_hidden: bool = False, _timing: bool = False) -> Predictions:
-        """``Estimator.predict`` (reference estimator.py:1035-1046)."""
+                _keep_hidden: bool = False, _timing: bool = False, _no_pack: bool = False) -> Predictions:
+        """``Estimator.predict`` (reference estimator.py:1035-1046).  ``_no_pack`` (test hook) keeps the padded row layout
+        through the encoder layers of a ragged batch (``AMX_FLAG_NO_PACK``)."""
         if self._spec.get("embedding_size"):
             if target_feature_indices is None:
                 if self._training_inventory is None:
@@ -303,6 +304,8 @@ class Estimator:
                 flags |= _lib.FLAG_KEEP_HIDDEN
             if _timing:
                 flags |= _lib.FLAG_TIMING
+            if _no_pack:
+                flags |= _lib.FLAG_NO_PACK
             stream = torch.cuda.current_stream(self._device).cuda_stream
             n_max = int(self._lib.amx_max_utterances(self._handle, L))
             if N <= n_max:

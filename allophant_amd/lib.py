@@ -16,7 +16,7 @@ AMX_NAME_LEN = 48
 
 AMX_OK, AMX_EINVAL, AMX_EHIP, AMX_ESTATE, AMX_ENOMEM = 0, -1, -2, -3, -4
 PRECISIONS = {"bf16": 0, "f16": 1, "bf16x3": 2, "f16x3": 3}
-FLAG_HOST_IO, FLAG_RAW_LOGITS, FLAG_KEEP_HIDDEN, FLAG_TIMING, FLAG_PADDED = 1, 2, 4, 8, 16
+FLAG_HOST_IO, FLAG_RAW_LOGITS, FLAG_KEEP_HIDDEN, FLAG_TIMING, FLAG_PADDED, FLAG_NO_PACK = 1, 2, 4, 8, 16, 32
 KERNEL_CLASSES = ["gemm_pp", "gemm_tile", "attention", "rownorm", "conv0", "other", "gemm_ln", "conv_tail"]
 DEP_OUTPUT = -1
 

@@ -51,6 +51,10 @@ extern "C" {
 #define AMX_FLAG_TIMING 8u       /* bracket every kernel launch with HIP events on the launch stream (amx_timing_fetch) */
 #define AMX_FLAG_PADDED 16u      /* L may exceed max(lengths): the call is one slice of a larger batch padded to L (the
                                     reference itself requires L == max(lengths), utils.py:62-63) */
+#define AMX_FLAG_NO_PACK 32u     /* keep the padded [N, T] row layout through the encoder layers even for a ragged batch (the
+                                    default runs them on the valid frames only; results on valid frames are identical) */
+#define AMX_FLAG_NO_PACK 32u     /* keep the padded [N, T] row layout through the encoder layers even for a ragged batch (the
+                                  * default runs them on the valid frames only; results on valid frames are identical) */
 
 /* kernel classes reported by amx_timing_fetch */
 #define AMX_KC_GEMM_PP 0   /* gemm_pp_kernel<T, NT, MI>: ping-pong GEMM on 256x256 / 128x256 tiles -- feature projection, QKV/out/FFN, wide heads */

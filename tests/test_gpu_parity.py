@@ -571,3 +571,67 @@ def test_other_baseline_configs_full_size_properties(amd, config):
         # (the batch and the solo run take differently tiled GEMM kernels: equal up to fp32 summation order)
         assert (pred.outputs[k][:ti, i] - solo.outputs[k][:ti, 0]).abs().max().item() < 5e-4, k
     est.close()
+
+
+def _custom_ragged(n, seconds, seed):
+    """Audio of `n` utterances with lengths from 25 % to 100 % of `seconds` (padding efficiency well below 0.9)."""
+    g = torch.Generator().manual_seed(seed)
+    longest = int(seconds * 16000)
+    lengths = torch.randint(longest // 4, longest + 1, (n,), generator=g)
+    lengths[int(torch.randint(0, n, (1,), generator=g))] = longest
+    audio = torch.randn(n, longest, generator=g) * 0.1
+    for i in range(n):
+        audio[i, int(lengths[i]):] = 0.0
+    return audio, lengths
+
+
+@pytest.mark.parametrize("shape,n,seconds", [("tiny", 7, 1.5), ("xlsr", 6, 8.0)])
+def test_packed_rows_give_the_bits_of_the_padded_layout(amd, shape, n, seconds):
+    """A ragged batch runs its encoder layers on the valid frames only (packed rows, utterances back to back; attention by
+    per-utterance row offsets).  Every row's arithmetic is independent of its position: where the products take the same
+    kernels in both layouts (the tiny model) the valid frames come out BITWISE equal to the padded layout
+    (`AMX_FLAG_NO_PACK`); at XLS-R shape the smaller row count changes tile heights / K chunks of some products, so the
+    two layouts agree like two batch compositions do (5e-4 of log-probability, far inside the gate).  Greedy alignments
+    equal, result within the gate of the oracle.  The timing hook shows that the packed path really ran (two more `other`
+    launches: pack, unpack)."""
+    from oracle import allophant_oracle as O
+
+    if shape == "tiny":
+        spec = S.multitask_spec(S.tiny_encoder(2), ["syllabic", "long", "nasal"], embedding_size=16, train_phonemes=9, n_features=5)
+    else:
+        spec = S.multitask_spec(S.xlsr_300m_encoder(), allophone_layer=True)
+        spec["shared_phones"] = 80
+    state = synthetic.make_state_dict(spec, seed=5)
+    tfi = synthetic.make_inventory(spec, 11, seed=5)
+    audio, lengths = _custom_ragged(n, seconds, seed=77)
+    est = amd.Estimator(spec, state, "cuda:0", "f16x3")
+    batch = amd.Batch(audio.cuda(), lengths, torch.zeros(n, dtype=torch.long))
+    est.timing_fetch()
+    packed = est.predict(batch, tfi, _timing=True)
+    launches_packed = est.timing_fetch()["other"][1]
+    padded = est.predict(batch, tfi, _timing=True, _no_pack=True)
+    launches_padded = est.timing_fetch()["other"][1]
+    assert launches_packed == launches_padded + 2, (launches_packed, launches_padded)
+    frames = packed.lengths.tolist()
+    assert sum(frames) * 10 <= len(frames) * max(frames) * 9  # ragged enough for the packed path
+    for name in packed.outputs:
+        for i, f in enumerate(frames):
+            if shape == "tiny":
+                assert torch.equal(packed.outputs[name][:f, i], padded.outputs[name][:f, i]), (name, i)
+            else:
+                assert (packed.outputs[name][:f, i] - padded.outputs[name][:f, i]).abs().max().item() < 5e-4, (name, i)
+    a, b = est.greedy_decode(packed), est.greedy_decode(padded)
+    for name in a:
+        for x, y in zip(a[name], b[name]):
+            assert torch.equal(x[0].tokens, y[0].tokens) and torch.equal(x[0].timesteps, y[0].timesteps)
+    # alternating layouts on one handle (the Q / K / V planes are shared): still the same bits
+    again = est.predict(batch, tfi)
+    for name in packed.outputs:
+        for i, f in enumerate(frames):
+            assert torch.equal(again.outputs[name][:f, i], packed.outputs[name][:f, i]), (name, i)
+    if shape == "tiny" or os.environ.get("AMX_SLOW_ORACLE", "1") == "1":
+        ref, ref_len = O.predict(audio, lengths, state, spec, tfi, synthetic.category_offsets(spec))
+        assert torch.equal(packed.lengths.cpu(), ref_len)
+        worst = max(max_abs_valid_tm(packed.outputs[k].cpu(), ref[k], ref_len) for k in ref)
+        assert worst < GATE, worst
+    est.close()
