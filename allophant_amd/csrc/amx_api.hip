@@ -957,9 +957,9 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     WS("hfin", (size_t)M * D * 4, hfin);
     WS("logits", (size_t)M * h->ld_logits * 4, logits);
     // Packed rows: a ragged batch runs its encoder layers on the valid frames only (rows of utterance n at row_off[n], all
-    // utterances back to back): every kernel of a layer is row-wise except the attention, which takes the offsets.  The
-    // results on valid frames are the same bits as in the padded layout (each row's arithmetic does not depend on its
-    // position).  Used when at least a tenth of the padded rows are padding and no caller needs per-layer hidden states in
+    // utterances back to back): every kernel of a layer is row-wise except the attention, which takes the offsets.  A row's
+    // arithmetic does not depend on its position, so the valid frames come out as in the padded layout (the same bits when
+    // the products pick the same kernels for the smaller row count, within rounding of the K-chunk order otherwise).  Used when at least a tenth of the padded rows are padding and no caller needs per-layer hidden states in
     // the padded layout; AMX_FLAG_NO_PACK / AMX_NO_PACKED_ROWS=1 keep the padded layout.
     static const bool no_pack_env = getenv("AMX_NO_PACKED_ROWS") && atoi(getenv("AMX_NO_PACKED_ROWS")) != 0;
     bool any_hidden = keep;
