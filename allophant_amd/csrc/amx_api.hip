@@ -118,6 +118,7 @@ struct amx_handle_s {
     int64_t* h_lengths_pinned[PIN_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     int* h_frames_pinned[PIN_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     int* h_rowoff_pinned[PIN_SLOTS] = {nullptr, nullptr, nullptr, nullptr};  // packed-row offsets of the utterances (N + 1)
+    int* h_convrows_pinned[PIN_SLOTS] = {nullptr, nullptr, nullptr, nullptr};  // [conv layer][N] valid output rows
     hipEvent_t pin_event[PIN_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     bool pin_busy[PIN_SLOTS] = {false, false, false, false};
     int pin_next = 0;
@@ -604,6 +605,7 @@ extern "C" int amx_destroy(amx_handle h) {
         if (h->h_lengths_pinned[i]) (void)hipHostFree(h->h_lengths_pinned[i]);
         if (h->h_frames_pinned[i]) (void)hipHostFree(h->h_frames_pinned[i]);
         if (h->h_rowoff_pinned[i]) (void)hipHostFree(h->h_rowoff_pinned[i]);
+        if (h->h_convrows_pinned[i]) (void)hipHostFree(h->h_convrows_pinned[i]);
         if (h->pin_event[i]) (void)hipEventDestroy(h->pin_event[i]);
     }
     for (auto& sp : h->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
@@ -892,10 +894,12 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
                 (void)hipHostFree(h->h_lengths_pinned[i]);
                 (void)hipHostFree(h->h_frames_pinned[i]);
                 (void)hipHostFree(h->h_rowoff_pinned[i]);
+                (void)hipHostFree(h->h_convrows_pinned[i]);
             }
             HIPCHK(h, hipHostMalloc((void**)&h->h_lengths_pinned[i], (size_t)N * 8));
             HIPCHK(h, hipHostMalloc((void**)&h->h_frames_pinned[i], (size_t)N * 4));
             HIPCHK(h, hipHostMalloc((void**)&h->h_rowoff_pinned[i], (size_t)(N + 1) * 4));
+            HIPCHK(h, hipHostMalloc((void**)&h->h_convrows_pinned[i], (size_t)N * AMX_MAX_CONV * 4));
             if (!h->pin_event[i]) HIPCHK(h, hipEventCreateWithFlags(&h->pin_event[i], hipEventDisableTiming));
             h->pin_busy[i] = false;
         }
@@ -907,9 +911,17 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     int64_t* pin_len = h->h_lengths_pinned[slot];
     int* pin_frames = h->h_frames_pinned[slot];
     int* pin_rowoff = h->h_rowoff_pinned[slot];
+    int* pin_convrows = h->h_convrows_pinned[slot];
     int64_t Mp = 0;  // valid frames of the batch = rows of the packed layout
     for (int n = 0; n < N; ++n) {
         pin_len[n] = lengths[n];
+        {
+            int64_t len_i = lengths[n];  // valid output rows of every conv layer (floor arithmetic of frontend.py:192-203)
+            for (int i = 0; i < c.n_conv; ++i) {
+                len_i = len_i < c.conv_kernel[i] ? 0 : (len_i - c.conv_kernel[i]) / c.conv_stride[i] + 1;
+                pin_convrows[(size_t)i * N + n] = (int)len_i;
+            }
+        }
         int64_t f = frames_of(c, lengths[n]);
         if (f < 1) return fail(h, AMX_EINVAL, "utterance shorter than the receptive field of the feature extractor");
         pin_frames[n] = (int)f;
@@ -938,8 +950,9 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     };
     WS("len", (size_t)N * 8, d_len);
     WS("frames", (size_t)N * 4, d_frames);
-    void* d_rowoff;
+    void *d_rowoff, *d_convrows;
     WS("rowoff", (size_t)(N + 1) * 4, d_rowoff);
+    WS("convrows", (size_t)N * AMX_MAX_CONV * 4, d_convrows);
     WS("partial", (size_t)N * 64 * 3 * 8, d_partial);
     WS("stats", (size_t)N * 2 * 4, d_stats);
     WS("actA", (size_t)rows1 * C * 2 * NT, actA);
@@ -1011,6 +1024,11 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     HIPCHK(h, hipMemcpyAsync(d_len, pin_len, (size_t)N * 8, hipMemcpyHostToDevice, s));
     HIPCHK(h, hipMemcpyAsync(d_frames, pin_frames, (size_t)N * 4, hipMemcpyHostToDevice, s));
     HIPCHK(h, hipMemcpyAsync(d_rowoff, pin_rowoff, (size_t)(N + 1) * 4, hipMemcpyHostToDevice, s));
+    // Ragged batch: the conv stack skips what lies wholly in an utterance's padding (conv0: frame blocks; the row-complete
+    // layers 1..n-2: 128-row tiles).  A valid frame of any layer only reads valid frames of the layer below, and the rows
+    // left unwritten (stale, possibly non-finite) stay inside padded rows until the feature projection zeroes those.
+    const bool ragged = Mp < M && !keep && !no_pack_env && !(flags & AMX_FLAG_NO_PACK);
+    if (ragged) HIPCHK(h, hipMemcpyAsync(d_convrows, pin_convrows, (size_t)N * c.n_conv * 4, hipMemcpyHostToDevice, s));
     HIPCHK(h, hipEventRecord(h->pin_event[slot], s));
     h->pin_busy[slot] = true;
 
@@ -1018,7 +1036,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     { Timed t_(h, AMX_KC_OTHER); launch_audio_stats(d_audio, (const int64_t*)d_len, N, L, (double*)d_partial, (float*)d_stats, c.do_normalize, s); }
     { Timed t_(h, AMX_KC_CONV0); launch_conv0(prec, d_audio, (const int64_t*)d_len, (const float*)d_stats, N, L, (int)Ts[1], C, c.conv_kernel[0],
                  c.conv_stride[0], h->c0_w, h->conv_b[0], h->conv_g[0], h->conv_be[0], 1e-5f, c.do_normalize, actA,
-                 rows1 * C, s); }
+                 rows1 * C, ragged ? 1 : 0, s); }
     // ---- conv layers 1..n-1: implicit GEMM over overlapping channels-last windows, then LN + GELU rows ----
     void* cur = actA;
     int64_t cur_plane = rows1 * C;
@@ -1031,6 +1049,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         g.W = h->conv_w[i]; g.w_plane = (int64_t)C * C * c.conv_kernel[i]; g.ldw = (int64_t)C * c.conv_kernel[i];
         g.M = (int)rows_out; g.N = C; g.K = C * c.conv_kernel[i];
         g.scale = 1.f; g.bias = h->conv_b[i];
+        g.row_valid = ragged ? (const int*)d_convrows + (size_t)i * N : nullptr;  // honoured by the row-complete kernel only
         const bool last = i == c.n_conv - 1;
         const int64_t out_plane = rows_out * C;
         if (!last) {

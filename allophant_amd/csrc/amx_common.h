@@ -202,6 +202,9 @@ struct GemmParams {
     int64_t splitk_ws_elems;  // capacity in floats
     int splits;               // internal (kernel view): number of K chunks, K = chunk length
     int64_t split_out;        // internal: distance between partial slabs (elements)
+    // ragged batches (row-complete conv kernel only): valid output rows of every batch item; a tile that lies inside the
+    // padding of one item is neither computed nor stored (null: every row is computed)
+    const int* row_valid;
     unsigned long long* stamps;  // developer diagnostic (-DAMX_PP_STAMP builds of tools/gemm_bench.hip), else null
 };
 
@@ -242,12 +245,13 @@ void launch_audio_stats(const float* audio, const int64_t* lengths, int N, int64
 // conv layer 0 (C_in = 1) + LayerNorm(C) + GELU, fused; writes planes [N*T1, C]
 void launch_conv0(int prec, const float* audio, const int64_t* lengths, const float* mean_rstd, int N, int64_t L, int T1,
                   int C, int k, int stride, const float* w /*[C,k]*/, const float* b, const float* gamma,
-                  const float* beta, float eps, int do_normalize, void* out, int64_t out_plane, hipStream_t s);
-// rows of width D: [LN1 -> GELU] (if gamma1) then [LN2] (if gamma2); outputs planes and/or f32
+                  const float* beta, float eps, int do_normalize, void* out, int64_t out_plane, int skip_padding, hipStream_t s);
+// (skip_padding: frame blocks that start beyond an utterance's own frames are not computed -- ragged batches)
 // rows of the padded [N, T, D] fp32 matrix <-> rows of the packed [sum(frame_len), D] matrix (utterance n at row_off[n]);
 // only rows t < frame_len[n] move
 void launch_pack_rows(const float* padded, float* packed, const int* row_off, const int* frame_len, int N, int T, int D, bool unpack,
                       hipStream_t s);
+// rows of width D: [LN1 -> GELU] (if gamma1) then [LN2] (if gamma2); outputs planes and/or f32
 void launch_rownorm(int prec, const float* x, int64_t ldx, int64_t M, int D, const float* gamma1, const float* beta1,
                     int gelu, const float* gamma2, const float* beta2, float eps1, float eps2, void* out_p,
                     int64_t out_plane, int64_t ldp, float* out_f32, int64_t ldo, hipStream_t s);

@@ -77,15 +77,18 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ au
                                                     const float* __restrict__ mean_rstd, int64_t L, int T1, int C, int k,
                                                     int stride, const float* __restrict__ w, const float* __restrict__ b,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                    float eps, int do_normalize, T* __restrict__ out, int64_t out_plane) {
+                                                    float eps, int do_normalize, T* __restrict__ out, int64_t out_plane,
+                                                    int skip_padding) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* win = (float*)smem;
     const int n = blockIdx.y;
     const int f0 = blockIdx.x * C0_FRAMES;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nwin = C0_FRAMES * stride + k;
-    const float mean = mean_rstd[2 * n], rstd = mean_rstd[2 * n + 1];
     const int64_t len = lengths[n];
+    // ragged batch: frames past the utterance's own (len - k) / stride + 1 feed no valid frame of any later layer
+    if (skip_padding && (int64_t)f0 * stride + k > len && f0 > 0) return;
+    const float mean = mean_rstd[2 * n], rstd = mean_rstd[2 * n + 1];
     const int64_t s0 = (int64_t)f0 * stride;
     for (int i = threadIdx.x; i < nwin; i += 256) {
         int64_t pos = s0 + i;
@@ -801,13 +804,14 @@ void launch_audio_stats(const float* audio, const int64_t* lengths, int N, int64
 template <typename T, int NT, int KW>
 static void conv0_launch_cpl(const float* audio, const int64_t* lengths, const float* mean_rstd, int N, int64_t L, int T1,
                              int C, int k, int stride, const float* w, const float* b, const float* gamma,
-                             const float* beta, float eps, int do_normalize, void* out, int64_t out_plane, hipStream_t s) {
+                             const float* beta, float eps, int do_normalize, void* out, int64_t out_plane, int skip_padding,
+                             hipStream_t s) {
     dim3 grid((T1 + C0_FRAMES - 1) / C0_FRAMES, N);
     size_t lds = (size_t)(C0_FRAMES * stride + k) * sizeof(float);
     int cpl = C >= 64 ? C / 64 : 1;
 #define C0_GO(CPL)                                                                                                  \
     hipLaunchKernelGGL((conv0_kernel<T, NT, CPL, KW>), grid, dim3(256), lds, s, audio, lengths, mean_rstd, L, T1, C, k, \
-                       stride, w, b, gamma, beta, eps, do_normalize, (T*)out, out_plane)
+                       stride, w, b, gamma, beta, eps, do_normalize, (T*)out, out_plane, skip_padding)
     if (cpl == 8) C0_GO(8);
     else if (cpl == 4) C0_GO(4);
     else if (cpl == 2) C0_GO(2);
@@ -817,13 +821,13 @@ static void conv0_launch_cpl(const float* audio, const int64_t* lengths, const f
 
 void launch_conv0(int prec, const float* audio, const int64_t* lengths, const float* mean_rstd, int N, int64_t L, int T1,
                   int C, int k, int stride, const float* w, const float* b, const float* gamma, const float* beta,
-                  float eps, int do_normalize, void* out, int64_t out_plane, hipStream_t s) {
+                  float eps, int do_normalize, void* out, int64_t out_plane, int skip_padding, hipStream_t s) {
     if (k == 10) {
         AMX_DISPATCH(prec, (conv0_launch_cpl<T16, NT, 10>(audio, lengths, mean_rstd, N, L, T1, C, k, stride, w, b, gamma, beta,
-                                                         eps, do_normalize, out, out_plane, s)));
+                                                         eps, do_normalize, out, out_plane, skip_padding, s)));
     } else {
         AMX_DISPATCH(prec, (conv0_launch_cpl<T16, NT, 16>(audio, lengths, mean_rstd, N, L, T1, C, k, stride, w, b, gamma, beta,
-                                                         eps, do_normalize, out, out_plane, s)));
+                                                         eps, do_normalize, out, out_plane, skip_padding, s)));
     }
 }
 
