@@ -39,7 +39,9 @@ constexpr float DEFER_THR = 8.0f;  // log2 units
 #define AMX_ATTN_OCC ((WAVES == 8 || KT == 32) ? 4 : 2)
 #endif
 // KT = keys per tile (64; a 32-key instance with four 4-wave workgroups per CU was 5 % slower at 32 x 10 s)
-template <typename T, int NT, int WAVES, int KT>
+// PACKED: the packed-row layout of a ragged batch (AttnParams.row_off), a compile-time variant so that the padded kernel
+// keeps its code
+template <typename T, int NT, int WAVES, int KT, bool PACKED>
 __global__ __launch_bounds__(WAVES * 64, AMX_ATTN_OCC) void attn_kernel(const AttnParams p) {
     constexpr int TILE = KT * 128;     // bytes of one K or V tile of one plane
     constexpr int NC = KT / 32;        // 32-key blocks per tile
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(WAVES * 64, AMX_ATTN_OCC) void attn_kernel(const At
     const int nkt = (klen + KT - 1) / KT;
     // packed rows: the utterance starts at row row_off[n] of every head's [Tp, 64] block; query blocks past its end do
     // not exist (in the padded layout they are computed like the reference computes them: the rows feed later kernels)
-    const bool packed = p.row_off != nullptr;
+    constexpr bool packed = PACKED;
     const int roff = packed ? p.row_off[n] : 0;
     if (packed && qblock * QB >= klen) return;
     const int64_t first = packed ? ((int64_t)h * p.Tp + roff) * DH : (int64_t)nh * p.Tp * DH;  // element offset of row 0
@@ -347,8 +349,8 @@ __global__ __launch_bounds__(WAVES * 64, AMX_ATTN_OCC) void attn_kernel(const At
 #endif
 }
 
-template <typename T, int NT, int WAVES, int KT>
-void launch_attn(const AttnParams& p, hipStream_t stream) {
+template <typename T, int NT, int WAVES, int KT, bool PACKED>
+void launch_attn_layout(const AttnParams& p, hipStream_t stream) {
 #ifdef AMX_ATTN_ABL_ONE_WG  // developer ablation: pad the LDS request so that only one workgroup fits a CU
     constexpr int lds = 100 * 1024;
 #else
@@ -356,10 +358,16 @@ void launch_attn(const AttnParams& p, hipStream_t stream) {
 #endif
     static OncePerDevice attr;
     if (attr.first())
-        (void)hipFuncSetAttribute((const void*)attn_kernel<T, NT, WAVES, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)attn_kernel<T, NT, WAVES, KT, PACKED>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const int qblocks = (p.T + WAVES * 32 - 1) / (WAVES * 32);
     dim3 grid((unsigned)(8 * ((p.N * p.H + 7) / 8) * qblocks));
-    hipLaunchKernelGGL((attn_kernel<T, NT, WAVES, KT>), grid, dim3(WAVES * 64), lds, stream, p);
+    hipLaunchKernelGGL((attn_kernel<T, NT, WAVES, KT, PACKED>), grid, dim3(WAVES * 64), lds, stream, p);
+}
+
+template <typename T, int NT, int WAVES, int KT>
+void launch_attn(const AttnParams& p, hipStream_t stream) {
+    if (p.row_off) launch_attn_layout<T, NT, WAVES, KT, true>(p, stream);
+    else launch_attn_layout<T, NT, WAVES, KT, false>(p, stream);
 }
 
 }  // namespace
