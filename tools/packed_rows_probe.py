@@ -37,6 +37,11 @@ for label, no_pack in (("packed rows", False), ("padded rows", True), ("packed r
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 10
     frames = int(pred.lengths.sum())
+    est.timing_fetch()
+    for _ in range(5):
+        est.predict(batch, tfi, _no_pack=no_pack, _timing=True)
+    torch.cuda.synchronize()
+    classes = " ".join(f"{k}={v[0] / 5:.2f}" for k, v in est.timing_fetch().items())
     print(f"{prec} {n} utterances U[{lo:g}, {hi:g}] s, padding efficiency {frames / (n * int(pred.lengths.max())):.3f}: {label} "
-          f"{dt * 1e3:7.3f} ms/step = {frames / dt:9.0f} valid frames/s", flush=True)
+          f"{dt * 1e3:7.3f} ms/step = {frames / dt:9.0f} valid frames/s   [{classes}]", flush=True)
 est.close()
