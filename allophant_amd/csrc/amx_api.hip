@@ -118,7 +118,8 @@ struct amx_handle_s {
     int64_t* h_lengths_pinned[PIN_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     int* h_frames_pinned[PIN_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     int* h_rowoff_pinned[PIN_SLOTS] = {nullptr, nullptr, nullptr, nullptr};  // packed-row offsets of the utterances (N + 1)
-    int* h_convrows_pinned[PIN_SLOTS] = {nullptr, nullptr, nullptr, nullptr};  // [conv layer][N] valid output rows
+    int* h_tiles_pinned[PIN_SLOTS] = {nullptr, nullptr, nullptr, nullptr};  // tile lists of the conv layers of a ragged batch
+    size_t tiles_cap[PIN_SLOTS] = {0, 0, 0, 0};                                // capacity of each, in ints
     hipEvent_t pin_event[PIN_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     bool pin_busy[PIN_SLOTS] = {false, false, false, false};
     int pin_next = 0;
@@ -605,7 +606,7 @@ extern "C" int amx_destroy(amx_handle h) {
         if (h->h_lengths_pinned[i]) (void)hipHostFree(h->h_lengths_pinned[i]);
         if (h->h_frames_pinned[i]) (void)hipHostFree(h->h_frames_pinned[i]);
         if (h->h_rowoff_pinned[i]) (void)hipHostFree(h->h_rowoff_pinned[i]);
-        if (h->h_convrows_pinned[i]) (void)hipHostFree(h->h_convrows_pinned[i]);
+        if (h->h_tiles_pinned[i]) (void)hipHostFree(h->h_tiles_pinned[i]);
         if (h->pin_event[i]) (void)hipEventDestroy(h->pin_event[i]);
     }
     for (auto& sp : h->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
@@ -894,12 +895,10 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
                 (void)hipHostFree(h->h_lengths_pinned[i]);
                 (void)hipHostFree(h->h_frames_pinned[i]);
                 (void)hipHostFree(h->h_rowoff_pinned[i]);
-                (void)hipHostFree(h->h_convrows_pinned[i]);
             }
             HIPCHK(h, hipHostMalloc((void**)&h->h_lengths_pinned[i], (size_t)N * 8));
             HIPCHK(h, hipHostMalloc((void**)&h->h_frames_pinned[i], (size_t)N * 4));
             HIPCHK(h, hipHostMalloc((void**)&h->h_rowoff_pinned[i], (size_t)(N + 1) * 4));
-            HIPCHK(h, hipHostMalloc((void**)&h->h_convrows_pinned[i], (size_t)N * AMX_MAX_CONV * 4));
             if (!h->pin_event[i]) HIPCHK(h, hipEventCreateWithFlags(&h->pin_event[i], hipEventDisableTiming));
             h->pin_busy[i] = false;
         }
@@ -911,7 +910,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     int64_t* pin_len = h->h_lengths_pinned[slot];
     int* pin_frames = h->h_frames_pinned[slot];
     int* pin_rowoff = h->h_rowoff_pinned[slot];
-    int* pin_convrows = h->h_convrows_pinned[slot];
+    std::vector<int> conv_rows((size_t)c.n_conv * N);  // [conv layer][n]: valid output rows
     int64_t Mp = 0;  // valid frames of the batch = rows of the packed layout
     for (int n = 0; n < N; ++n) {
         pin_len[n] = lengths[n];
@@ -919,7 +918,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             int64_t len_i = lengths[n];  // valid output rows of every conv layer (floor arithmetic of frontend.py:192-203)
             for (int i = 0; i < c.n_conv; ++i) {
                 len_i = len_i < c.conv_kernel[i] ? 0 : (len_i - c.conv_kernel[i]) / c.conv_stride[i] + 1;
-                pin_convrows[(size_t)i * N + n] = (int)len_i;
+                conv_rows[(size_t)i * N + n] = (int)len_i;
             }
         }
         int64_t f = frames_of(c, lengths[n]);
@@ -950,9 +949,8 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     };
     WS("len", (size_t)N * 8, d_len);
     WS("frames", (size_t)N * 4, d_frames);
-    void *d_rowoff, *d_convrows;
+    void* d_rowoff;
     WS("rowoff", (size_t)(N + 1) * 4, d_rowoff);
-    WS("convrows", (size_t)N * AMX_MAX_CONV * 4, d_convrows);
     WS("partial", (size_t)N * 64 * 3 * 8, d_partial);
     WS("stats", (size_t)N * 2 * 4, d_stats);
     WS("actA", (size_t)rows1 * C * 2 * NT, actA);
@@ -1028,7 +1026,37 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     // layers 1..n-2: 128-row tiles).  A valid frame of any layer only reads valid frames of the layer below, and the rows
     // left unwritten (stale, possibly non-finite) stay inside padded rows until the feature projection zeroes those.
     const bool ragged = Mp < M && !keep && !no_pack_env && !(flags & AMX_FLAG_NO_PACK);
-    if (ragged) HIPCHK(h, hipMemcpyAsync(d_convrows, pin_convrows, (size_t)N * c.n_conv * 4, hipMemcpyHostToDevice, s));
+    // per conv layer i >= 1: the ascending list of its 128-row output tiles that hold a row some utterance owns
+    int* d_tiles = nullptr;
+    size_t tile_first[AMX_MAX_CONV + 1] = {0};
+    if (ragged) {
+        size_t total_tiles = 0;
+        for (int i = 1; i < c.n_conv; ++i) total_tiles += (size_t)((N * Ts[i + 1] + 127) / 128);
+        if (h->tiles_cap[slot] < total_tiles) {  // the slot is idle: its event was waited for above
+            if (h->h_tiles_pinned[slot]) (void)hipHostFree(h->h_tiles_pinned[slot]);
+            h->h_tiles_pinned[slot] = nullptr;
+            h->tiles_cap[slot] = 0;
+            HIPCHK(h, hipHostMalloc((void**)&h->h_tiles_pinned[slot], (total_tiles + total_tiles / 4 + 64) * 4));
+            h->tiles_cap[slot] = total_tiles + total_tiles / 4 + 64;
+        }
+        int* list = h->h_tiles_pinned[slot];
+        size_t count = 0;
+        for (int i = 1; i < c.n_conv; ++i) {
+            tile_first[i] = count;
+            const int64_t rpb = Ts[i + 1], rows = N * rpb;
+            const int* valid = conv_rows.data() + (size_t)i * N;
+            for (int64_t first = 0; first < rows; first += 128) {
+                const int64_t last = std::min(first + 128, rows) - 1;
+                const int64_t b0 = first / rpb, b1 = last / rpb;
+                if (b0 != b1 || first - b0 * rpb < valid[b0]) list[count++] = (int)(first / 128);
+            }
+        }
+        tile_first[c.n_conv] = count;
+        void* p;
+        WS("conv_tiles", std::max<size_t>(count, 1) * 4, p);
+        d_tiles = (int*)p;
+        HIPCHK(h, hipMemcpyAsync(d_tiles, list, count * 4, hipMemcpyHostToDevice, s));
+    }
     HIPCHK(h, hipEventRecord(h->pin_event[slot], s));
     h->pin_busy[slot] = true;
 
@@ -1049,7 +1077,10 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         g.W = h->conv_w[i]; g.w_plane = (int64_t)C * C * c.conv_kernel[i]; g.ldw = (int64_t)C * c.conv_kernel[i];
         g.M = (int)rows_out; g.N = C; g.K = C * c.conv_kernel[i];
         g.scale = 1.f; g.bias = h->conv_b[i];
-        g.row_valid = ragged ? (const int*)d_convrows + (size_t)i * N : nullptr;  // honoured by the row-complete kernel only
+        if (ragged) {  // honoured by the row-complete kernel only
+            g.tile_list = d_tiles + tile_first[i];
+            g.n_tiles = (int)(tile_first[i + 1] - tile_first[i]);
+        }
         const bool last = i == c.n_conv - 1;
         const int64_t out_plane = rows_out * C;
         if (!last) {

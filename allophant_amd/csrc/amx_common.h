@@ -202,9 +202,10 @@ struct GemmParams {
     int64_t splitk_ws_elems;  // capacity in floats
     int splits;               // internal (kernel view): number of K chunks, K = chunk length
     int64_t split_out;        // internal: distance between partial slabs (elements)
-    // ragged batches (row-complete conv kernel only): valid output rows of every batch item; a tile that lies inside the
-    // padding of one item is neither computed nor stored (null: every row is computed)
-    const int* row_valid;
+    // ragged batches (row-complete conv kernel only): the 128-row tiles to compute, ascending (the tiles that lie wholly inside
+    // the padding of one batch item are left out: neither computed nor stored); null: every tile
+    const int* tile_list;
+    int n_tiles;
     unsigned long long* stamps;  // developer diagnostic (-DAMX_PP_STAMP builds of tools/gemm_bench.hip), else null
 };
 

@@ -66,7 +66,8 @@ void launch_gemm_ln(const GemmParams& p, hipStream_t stream) {
     static OncePerDevice attr;
     if (attr.first())
         (void)hipFuncSetAttribute((const void*)gemm_ln_kernel<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, ppw::LDS_BYTES);
-    const int tiles = (p.M + ppw::BM - 1) / ppw::BM;
+    const int tiles = p.tile_list ? p.n_tiles : (p.M + ppw::BM - 1) / ppw::BM;
+    if (tiles <= 0) return;
     const int cus = device_cus();
     dim3 grid(tiles < cus ? tiles : cus, 1, 1);
     hipLaunchKernelGGL((gemm_ln_kernel<T, NT>), grid, dim3(512), ppw::LDS_BYTES, stream, p);
