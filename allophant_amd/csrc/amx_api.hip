@@ -970,11 +970,11 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     // Packed rows: a ragged batch runs its encoder layers on the valid frames only (rows of utterance n at row_off[n], all
     // utterances back to back): every kernel of a layer is row-wise except the attention, which takes the offsets.  A row's
     // arithmetic does not depend on its position, so the valid frames come out as in the padded layout (the same bits when
-    // the products pick the same kernels for the smaller row count, within rounding of the K-chunk order otherwise).  Used when at least a tenth of the padded rows are padding and no caller needs per-layer hidden states in
-    // the padded layout; AMX_FLAG_NO_PACK / AMX_NO_PACKED_ROWS=1 keep the padded layout.
+    // the products pick the same kernels for the smaller row count, within rounding of the K-chunk order otherwise).  Used
+    // when at least a tenth of the padded rows are padding (not under AMX_FLAG_KEEP_HIDDEN); AMX_FLAG_NO_PACK /
+    // AMX_NO_PACKED_ROWS=1 keep the padded layout.
     static const bool no_pack_env = getenv("AMX_NO_PACKED_ROWS") && atoi(getenv("AMX_NO_PACKED_ROWS")) != 0;
-    bool any_hidden = keep;
-    for (int l = 0; l < c.layers; ++l) any_hidden = any_hidden || h->need_hidden[l];
+    const bool any_hidden = keep;  // the debug capture wants every hidden state in the padded layout, padding included
     const int TpTot = round_up((int)Mp, 64) + 64;  // rows per head of the packed Q / K / V planes
     const bool packed = !no_pack_env && !(flags & AMX_FLAG_NO_PACK) && !any_hidden && D % 4 == 0 && Mp * 10 <= M * 9 &&
                         (int64_t)TpTot <= (int64_t)N * Tp;
@@ -1160,7 +1160,12 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     const int64_t qk_plane = packed ? (int64_t)H * TpTot * 64 : (int64_t)N * H * Tp * 64;
     for (int l = 0; l < c.layers; ++l) {
         const Layer& ly = h->layers[l];
-        if (saved[l]) HIPCHK(h, hipMemcpyAsync(saved[l], hbuf, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s));
+        if (saved[l]) {
+            // a classifier reads hidden state l (OUTPUT_l, acoustic_model.py:478-483): padded layout; with packed rows the padded
+            // frames take their pre-encoder rows (finite, as meaningless as any padded frame) and the valid ones are scattered in
+            HIPCHK(h, hipMemcpyAsync(saved[l], packed ? hpad : hbuf, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s));
+            if (packed) launch_pack_rows(saved[l], (float*)hbuf, (const int*)d_rowoff, (const int*)d_frames, N, T, D, true, s);
+        }
         { Timed t_(h, AMX_KC_ROWNORM); launch_rownorm(prec, (const float*)hbuf, D, Mrows, D, ly.ln1_g, ly.ln1_b, 0, nullptr, nullptr, c.eps, 0.f, xp, xp_plane, D,
                        nullptr, 0, s); }
         {
