@@ -173,6 +173,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=4)
     ap.add_argument("--decoded-gather", action="store_true",
                     help="N > 1: also time the step that gathers greedy CTC alignments of the phoneme output instead of log-probs")
+    ap.add_argument("--no-ragged", action="store_true", help="N = 1: skip the informational ragged-batch leg")
     ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the weak-scaling leg (32 x 10 s per GPU)")
     args = ap.parse_args()
 
@@ -441,6 +442,40 @@ def main():
                 "note": "single 16-bit plane per operand (1 MFMA per product); max-abs log-prob error vs the reference "
                         "2.3e-1 (bf16) / 3.0e-2 (f16) at XLS-R shape, see DESIGN.md section 3 -- NOT a parity mode",
             }
+    # N = 1: what a ragged batch gets (informational; `value` is the equal-length config above): the encoder layers run on the
+    # valid frames only and the conv stack skips tiles that lie in padding, against the padded layout of the same batch
+    if world == 1 and not args.no_ragged:
+        try:
+            g = torch.Generator().manual_seed(9)
+            r_lengths = torch.randint(int(0.2 * length), length + 1, (n_global,), generator=g)
+            r_lengths[0] = length
+            r_audio = torch.randn(n_global, length, generator=g) * 0.1
+            for i in range(n_global):
+                r_audio[i, int(r_lengths[i]):] = 0.0
+            r_batch = Batch(r_audio.to(device), r_lengths, torch.zeros(n_global, dtype=torch.long))
+            est = Estimator(spec, state, device, args.precision)
+            timings = {}
+            for label, no_pack in (("packed", False), ("padded", True)):
+                for _ in range(args.warmup):
+                    pred = est.predict(r_batch, tfi, True, _no_pack=no_pack)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    pred = est.predict(r_batch, tfi, True, _no_pack=no_pack)
+                torch.cuda.synchronize()
+                timings[label] = (time.perf_counter() - t0) / args.steps
+            valid = int(pred.lengths.sum())
+            est.close()
+            result["ragged_batch"] = {
+                "workload": f"{n_global} utterances of U[{0.2 * args.seconds:g}, {args.seconds:g}] s padded to {args.seconds:g} s, same model",
+                "padding_efficiency": valid / (n_global * int(pred.lengths.max())),
+                "value": valid / timings["packed"], "unit": "valid frames/s", "ms_per_step": timings["packed"] * 1e3,
+                "padded_layout_ms_per_step": timings["padded"] * 1e3,
+                "note": "encoder layers on packed rows + conv stack skipping padding tiles (default for ragged batches) against "
+                        "AMX_FLAG_NO_PACK, which computes every padded frame like the reference",
+            }
+        except Exception as exc:  # informational leg: never costs the headline
+            result["ragged_batch"] = {"error": repr(exc)}
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(spec, state, tfi, args.cpu_sample, length)
