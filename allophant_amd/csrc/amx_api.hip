@@ -1031,7 +1031,8 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     size_t tile_first[AMX_MAX_CONV + 1] = {0};
     if (ragged) {
         size_t total_tiles = 0;
-        for (int i = 1; i < c.n_conv; ++i) total_tiles += (size_t)((N * Ts[i + 1] + 127) / 128);
+        constexpr int64_t TR = GEMM_LN_TILE_ROWS;
+        for (int i = 1; i < c.n_conv; ++i) total_tiles += (size_t)((N * Ts[i + 1] + TR - 1) / TR);
         if (h->tiles_cap[slot] < total_tiles) {  // the slot is idle: its event was waited for above
             if (h->h_tiles_pinned[slot]) (void)hipHostFree(h->h_tiles_pinned[slot]);
             h->h_tiles_pinned[slot] = nullptr;
@@ -1045,10 +1046,10 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             tile_first[i] = count;
             const int64_t rpb = Ts[i + 1], rows = N * rpb;
             const int* valid = conv_rows.data() + (size_t)i * N;
-            for (int64_t first = 0; first < rows; first += 128) {
-                const int64_t last = std::min(first + 128, rows) - 1;
+            for (int64_t first = 0; first < rows; first += TR) {
+                const int64_t last = std::min(first + TR, rows) - 1;
                 const int64_t b0 = first / rpb, b1 = last / rpb;
-                if (b0 != b1 || first - b0 * rpb < valid[b0]) list[count++] = (int)(first / 128);
+                if (b0 != b1 || first - b0 * rpb < valid[b0]) list[count++] = (int)(first / TR);
             }
         }
         tile_first[c.n_conv] = count;

@@ -156,6 +156,8 @@ struct OncePerDevice {
 // ---------------------------------------------------------------------------------------------------------------
 // GEMM:  C[M,N] = epilogue( A[M,K] . W[N,K]^T )      A and W are K-contiguous 16-bit planes
 // ---------------------------------------------------------------------------------------------------------------
+constexpr int GEMM_LN_TILE_ROWS = 128;  // tile height of the row-complete conv kernel (GemmParams.tile_list)
+
 struct GemmParams {
     // A operand: row r lives at A + (r / rows_per_batch) * a_batch_stride + (r % rows_per_batch) * lda  (elements).
     // Overlapping rows (lda < K) express the strided 1-D convolutions as implicit GEMMs over channels-last input.
@@ -204,7 +206,7 @@ struct GemmParams {
     int64_t split_out;        // internal: distance between partial slabs (elements)
     // ragged batches (row-complete conv kernel only): the 128-row tiles to compute, ascending (the tiles that lie wholly inside
     // the padding of one batch item are left out: neither computed nor stored); null: every tile
-    const int* tile_list;
+    const int* tile_list;  // tile index = first row / GEMM_LN_TILE_ROWS
     int n_tiles;
     unsigned long long* stamps;  // developer diagnostic (-DAMX_PP_STAMP builds of tools/gemm_bench.hip), else null
 };
