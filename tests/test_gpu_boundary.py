@@ -308,3 +308,58 @@ def test_decoded_gather_over_a_one_rank_rccl_group(amd):
             assert torch.equal(hyp.tokens, tokens) and torch.equal(hyp.timesteps, timesteps), name
             assert abs(hyp.score - float(score)) < 1e-3 * max(1.0, abs(float(score)))
     est.close()
+
+
+def test_c_abi_with_plain_host_buffers(amd):
+    """The boundary is plain pointers and sizes: drive `liballophant_amx.so` through ctypes with numpy arrays only -- weights,
+    audio, lengths, inventory and the output block are host memory (`AMX_FLAG_HOST_IO`: the library stages them over PCIe and
+    returns synchronised), the stream is the null stream -- and compare with the torch-tensor façade on the same model."""
+    import numpy as np
+
+    from allophant_amd import lib as L
+    from allophant_amd.estimator import _spec_to_structs
+
+    spec = S.multitask_spec(S.tiny_encoder(2), ["syllabic", "long"], embedding_size=16, train_phonemes=9, n_features=5)
+    state = synthetic.make_state_dict(spec, seed=12)
+    tfi = synthetic.make_inventory(spec, 10, seed=12)
+    audio, lengths = synthetic.make_audio(3, 20000, seed=12, ragged=True)
+    est = amd.Estimator(spec, state, "cuda:0")
+    want = est.predict(amd.Batch(audio.cuda(), lengths, torch.zeros(3, dtype=torch.long)), tfi)
+    want_out = {k: v.cpu().numpy() for k, v in want.outputs.items()}
+    est.close()
+
+    lib = L.load()
+    cfg, descs = _spec_to_structs(spec, "f16x3")
+    arrays = {k: np.ascontiguousarray(v.detach().cpu().numpy(), dtype=np.float32) for k, v in state.items()}
+    tensors = (L.AmxTensor * len(arrays))()
+    for i, (name, a) in enumerate(arrays.items()):
+        tensors[i].name = name.encode()
+        tensors[i].data = a.ctypes.data_as(C.POINTER(C.c_float))
+        tensors[i].numel = a.size
+    handle = C.c_void_p()
+    L.check(lib, None, lib.amx_create(C.byref(handle), 0, C.byref(cfg), descs, len(descs), tensors, len(arrays)))
+    try:
+        tfi_np = np.ascontiguousarray(tfi.numpy(), dtype=np.int64)
+        offsets = np.cumsum([1] + list(spec["composition_categories"]), dtype=np.int64)[:-1].copy()
+        L.check(lib, handle, lib.amx_set_inventory(handle, tfi_np.ctypes.data_as(C.POINTER(C.c_int64)), tfi_np.shape[0], tfi_np.shape[1],
+                                                   offsets.ctypes.data_as(C.POINTER(C.c_int64)), None))
+        audio_np = np.ascontiguousarray(audio.numpy(), dtype=np.float32)
+        len_np = np.ascontiguousarray(lengths.numpy(), dtype=np.int64)
+        n, l = audio_np.shape
+        n_out, t, total = C.c_int(), C.c_int64(), C.c_int64()
+        L.check(lib, handle, lib.amx_output_layout(handle, n, l, None, C.byref(n_out), C.byref(t), C.byref(total)))
+        layout = (L.AmxOutputDesc * n_out.value)()
+        L.check(lib, handle, lib.amx_output_layout(handle, n, l, layout, C.byref(n_out), C.byref(t), C.byref(total)))
+        out = np.empty(total.value, dtype=np.float32)
+        out_len = np.empty(n, dtype=np.int64)
+        L.check(lib, handle, lib.amx_forward(handle, C.c_void_p(audio_np.ctypes.data), len_np.ctypes.data_as(C.POINTER(C.c_int64)), n, l,
+                                             C.c_void_p(out.ctypes.data), out_len.ctypes.data_as(C.POINTER(C.c_int64)),
+                                             L.FLAG_HOST_IO, None))
+        assert out_len.tolist() == want.lengths.tolist()
+        for d in layout:
+            name = d.name.decode()
+            got = out[d.offset: d.offset + t.value * n * d.classes].reshape(t.value, n, d.classes)
+            for i, f in enumerate(out_len.tolist()):
+                assert np.array_equal(got[:f, i], want_out[name][:f, i]), name
+    finally:
+        lib.amx_destroy(handle)
