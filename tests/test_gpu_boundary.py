@@ -363,3 +363,29 @@ def test_c_abi_with_plain_host_buffers(amd):
                 assert np.array_equal(got[:f, i], want_out[name][:f, i]), name
     finally:
         lib.amx_destroy(handle)
+
+
+def test_small_entry_points(amd):
+    """`amx_device_bytes` (weights, then weights + workspace), `amx_synchronize`, and the ABI-version check of `amx_create`."""
+    from allophant_amd import lib as L
+    from allophant_amd.estimator import _spec_to_structs
+
+    spec = S.baseline_spec(S.tiny_encoder(1), 6)
+    state = synthetic.make_state_dict(spec, seed=2)
+    est = amd.Estimator(spec, state, "cuda:0")
+    weights_only = est.device_bytes
+    assert weights_only > 0
+    audio, lengths = synthetic.make_audio(2, 8000, seed=2)
+    est.predict(amd.Batch(audio.cuda(), lengths, torch.zeros(2, dtype=torch.long)))
+    est.synchronize()
+    assert est.device_bytes > weights_only  # the workspace of the first geometry
+    est.close()
+    # a binding built against another header is refused before anything is allocated
+    lib = L.load()
+    cfg, descs = _spec_to_structs(spec, "f16x3")
+    cfg.abi_version = L.AMX_ABI_VERSION + 1
+    handle = C.c_void_p()
+    code = lib.amx_create(C.byref(handle), 0, C.byref(cfg), descs, len(descs), (L.AmxTensor * 1)(), 0)
+    assert code != 0 and not handle.value
+    with pytest.raises(ValueError, match="ABI version"):
+        L.check(lib, None, code)
