@@ -898,7 +898,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             }
             HIPCHK(h, hipHostMalloc((void**)&h->h_lengths_pinned[i], (size_t)N * 8));
             HIPCHK(h, hipHostMalloc((void**)&h->h_frames_pinned[i], (size_t)N * 4));
-            HIPCHK(h, hipHostMalloc((void**)&h->h_rowoff_pinned[i], (size_t)(N + 1) * 4));
+            HIPCHK(h, hipHostMalloc((void**)&h->h_rowoff_pinned[i], (size_t)(2 * N + 1) * 4));  // offsets, then the order
             if (!h->pin_event[i]) HIPCHK(h, hipEventCreateWithFlags(&h->pin_event[i], hipEventDisableTiming));
             h->pin_busy[i] = false;
         }
@@ -929,6 +929,11 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         if (out_lengths) out_lengths[n] = f;
     }
     pin_rowoff[N] = (int)Mp;
+    {   // utterances by descending length (ties by index): the order the packed attention dispatches them in
+        int* order = pin_rowoff + N + 1;
+        for (int n = 0; n < N; ++n) order[n] = n;
+        std::stable_sort(order, order + N, [&](int a, int b) { return pin_frames[a] > pin_frames[b]; });
+    }
 
     // ---- workspace ----
     void *d_len, *d_frames, *d_partial, *d_stats, *actA, *actB, *preln, *hbuf, *xp, *hg, *qb, *kb, *vtb, *ao, *ff, *hfin, *logits;
@@ -950,7 +955,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     WS("len", (size_t)N * 8, d_len);
     WS("frames", (size_t)N * 4, d_frames);
     void* d_rowoff;
-    WS("rowoff", (size_t)(N + 1) * 4, d_rowoff);
+    WS("rowoff", (size_t)(2 * N + 1) * 4, d_rowoff);
     WS("partial", (size_t)N * 64 * 3 * 8, d_partial);
     WS("stats", (size_t)N * 2 * 4, d_stats);
     WS("actA", (size_t)rows1 * C * 2 * NT, actA);
@@ -1021,7 +1026,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
 
     HIPCHK(h, hipMemcpyAsync(d_len, pin_len, (size_t)N * 8, hipMemcpyHostToDevice, s));
     HIPCHK(h, hipMemcpyAsync(d_frames, pin_frames, (size_t)N * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(h, hipMemcpyAsync(d_rowoff, pin_rowoff, (size_t)(N + 1) * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(d_rowoff, pin_rowoff, (size_t)(2 * N + 1) * 4, hipMemcpyHostToDevice, s));
     // Ragged batch: the conv stack skips what lies wholly in an utterance's padding (conv0: frame blocks; the row-complete
     // layers 1..n-2: 128-row tiles).  A valid frame of any layer only reads valid frames of the layer below, and the rows
     // left unwritten (stale, possibly non-finite) stay inside padded rows until the feature projection zeroes those.
@@ -1189,6 +1194,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             a.frame_len = (const int*)d_frames;
             a.N = N; a.H = H; a.T = T; a.Tp = packed ? TpTot : Tp; a.dh = 64;
             a.row_off = packed ? (const int*)d_rowoff : nullptr;
+            a.order = packed ? (const int*)d_rowoff + N + 1 : nullptr;
             { Timed t_(h, AMX_KC_ATTENTION); launch_attention(prec, a, s); }
         }
         {

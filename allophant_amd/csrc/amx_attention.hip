@@ -68,7 +68,9 @@ __global__ __launch_bounds__(WAVES * 64, AMX_ATTN_OCC) void attn_kernel(const At
     const int nh = (slot / qblocks) * 8 + (blockIdx.x & 7);
     const int qblock = slot % qblocks;
     if (nh >= p.N * p.H) return;
-    const int n = nh / p.H, h = nh % p.H;
+    // a ragged batch is walked longest utterance first, so that the long workgroups do not start last
+    const int h = nh % p.H;
+    const int n = PACKED && p.order ? p.order[nh / p.H] : nh / p.H;
     const int q_base = qblock * QB + wave * 32;
     const int query = q_base + lq;
     int klen = p.frame_len[n];

@@ -236,6 +236,7 @@ struct AttnParams {
     // [H, Tp, dh] planes in which utterance n owns rows row_off[n] .. row_off[n] + frame_len[n] (Tp = rows per head, at
     // least 64 finite rows beyond the last utterance), `out` is [sum(frame_len), D] and only valid queries are computed
     const int* row_off;
+    const int* order;  // packed rows only, may be null: utterance indices, longest first (workgroups are dispatched in this order)
     unsigned long long* stamps;  // developer diagnostic (-DAMX_ATTN_STAMP builds of tools/attn_bench.hip), else null
 };
 void launch_attention(int prec, const AttnParams& p, hipStream_t stream);
