@@ -121,10 +121,12 @@ class PinnedCollator:
     def __init__(self, max_samples: int, depth: int = 3):
         self._buffers = [torch.empty(max_samples, dtype=torch.float32).pin_memory() for _ in range(depth)]
         self._events: List[Optional["torch.cuda.Event"]] = [None] * depth
+        self._handed_out = [False] * depth  # slot given to a caller since its last refill
         self._next = 0
 
     def mark_in_flight(self, batch: Batch, event: "torch.cuda.Event") -> None:
-        """``event`` completes once the device copy of ``batch`` (a batch this collator returned) has read its slot."""
+        """``event`` completes once the device copy of ``batch`` (a batch this collator returned) has read its slot.
+        ``Prefetcher`` and ``Batch.to(device, non_blocking=True)`` call this."""
         slot = getattr(batch, "_pinned_slot", None)
         if slot is not None and slot[0] is self:
             self._events[slot[1]] = event
@@ -135,12 +137,16 @@ class PinnedCollator:
         n = len(audio)
         slot = self._next
         buf = self._buffers[slot]
-        self._next = (self._next + 1) % len(self._buffers)
         if n * longest > buf.numel():
-            return collate(audio, language_ids, pin=True)  # over-long single utterance: one-off buffer
+            return collate(audio, language_ids, pin=True)  # over-long single utterance: one-off buffer, the ring stays put
+        self._next = (self._next + 1) % len(self._buffers)
         if self._events[slot] is not None:
             self._events[slot].synchronize()  # the copy out of this slot has finished
             self._events[slot] = None
+        elif self._handed_out[slot] and torch.cuda.is_available() and torch.cuda.is_initialized():
+            # the slot went out and nobody reported a copy event (a hand-rolled asynchronous copy): wait for everything
+            # rather than refill memory a host-to-device copy may still be reading
+            torch.cuda.synchronize()
         features = buf[: n * longest].view(n, longest)
         for i, a in enumerate(audio):
             k = a.numel()
@@ -150,6 +156,7 @@ class PinnedCollator:
         ids = torch.tensor(list(language_ids) if language_ids is not None else [0] * n, dtype=torch.int64)
         batch = Batch(features, lengths, ids)
         batch._pinned_slot = (self, slot)
+        self._handed_out[slot] = True
         return batch
 
 
@@ -158,14 +165,13 @@ class Prefetcher:
     on a side stream; because ``Estimator.predict`` only *launches* work, the caller's call for batch k+1 arrives while the
     GPU is still computing batch k, so the host-side collation and the host-to-device copy of k+1 overlap the compute of k
     (the compute stream waits for the copy only when it actually consumes the batch).  ``batches`` yields CPU ``Batch``
-    objects, or anything ``fetch`` turns into one (e.g. index lists).  ``collator``: the ``PinnedCollator`` the batches come
-    from, if any -- it is told when the copy out of a slot completes (event per slot)."""
+    objects, or anything ``fetch`` turns into one (e.g. index lists).  Batches that come out of a ``PinnedCollator`` carry
+    their slot with them; the collator is told the event behind which the copy out of that slot has completed."""
 
-    def __init__(self, batches: Iterable, device: torch.device, fetch=None, collator: Optional[PinnedCollator] = None):
+    def __init__(self, batches: Iterable, device: torch.device, fetch=None):
         self._source = iter(batches)
         self._device = torch.device(device)
         self._fetch = fetch
-        self._collator = collator
         self._stream = torch.cuda.Stream(self._device)
 
     @property

@@ -87,6 +87,7 @@ struct amx_handle_s {
         int64_t* idx_dev = nullptr;
         OutDesc *out_unique_dev = nullptr, *out_all_dev = nullptr;
         uint64_t last_use = 0;
+        uint64_t generation = 0;   // unique per install: a cached layout of an evicted entry never matches its successor
     };
     static constexpr int INV_CAP = 16;
     std::vector<Inventory> inventories;
@@ -102,7 +103,8 @@ struct amx_handle_s {
     std::vector<amx_output_desc> outputs;  // relative to N, T of the last layout computation
     std::vector<OutDesc> out_unique, out_all;
     OutDesc *out_unique_dev = nullptr, *out_all_dev = nullptr;  // of the current inventory
-    int layout_inv = -2;  // inventory the host-side layout was computed for
+    int layout_inv = -2;  // inventory slot the host-side layout was computed for ...
+    uint64_t layout_gen = 0, inv_gen = 0;  // ... and the install generation of that slot: slots are reused after eviction
     int layout_N = -1;
     int64_t layout_T = -1;
 
@@ -714,6 +716,7 @@ static int install_inventory(amx_handle h, std::vector<int64_t>&& key, const std
     // serves repeats), so the call simply waits for them instead of relying on the runtime's staging behaviour
     if (hipStreamSynchronize(s) != hipSuccess) return fail_free(AMX_EHIP, "inventory upload failed");
     e.key = std::move(key);
+    e.generation = ++h->inv_gen;
     select_inventory(h, slot);
     return AMX_OK;
 }
@@ -777,13 +780,14 @@ static int64_t max_utterances_for(const amx_config& c, int NT, int64_t L) {
     int64_t best = INT32_MAX / std::max<int64_t>(Ts[1], 1);           // 32-bit row indices of the first conv output
     best = std::min(best, (int64_t)INT32_MAX / std::max<int64_t>(T, 1));
     best = std::min(best, ((int64_t)INT32_MAX * 4 / wide) / std::max<int64_t>(T, 1));
-    if (NT > 1) {
-        // conv activations [N * Ts[i], C]: plane + one utterance (tiles crossing an utterance boundary)
-        for (int i = 1; i < c.n_conv; ++i) best = std::min(best, LIMIT / (Ts[i] * C * 2) - 1);
-        best = std::min(best, LIMIT / (T * wide * 2));        // FFN activation / fused QKV rows
-        best = std::min(best, LIMIT / (H * Tp * 64 * 2));     // Q / K / V planes
-        best = std::min(best, LIMIT / ((T + c.pos_kernel) * D * 2));  // padded image of the positional convolution
-    }
+    // one plane of every activation stays below 4 GiB in the single-plane modes too: the buffer loads of those kernels use
+    // the same 32-bit byte offsets (NT only decides whether a second plane follows)
+    (void)NT;
+    // conv activations [N * Ts[i], C]: plane + one utterance (tiles crossing an utterance boundary)
+    for (int i = 1; i < c.n_conv; ++i) best = std::min(best, LIMIT / (Ts[i] * C * 2) - 1);
+    best = std::min(best, LIMIT / (T * wide * 2));        // FFN activation / fused QKV rows
+    best = std::min(best, LIMIT / (H * Tp * 64 * 2));     // Q / K / V planes
+    best = std::min(best, LIMIT / ((T + c.pos_kernel) * D * 2));  // padded image of the positional convolution
     return std::max<int64_t>(best, 0);
 }
 
@@ -802,7 +806,8 @@ static int compute_layout(amx_handle h, int N, int64_t L) {
     if (T > 1 << 20) return fail(h, AMX_EINVAL, "utterance too long");
     if (h->inv < 0)
         return fail(h, AMX_ESTATE, "composition model needs amx_set_inventory before prediction (the training inventory is a non-persistent buffer upstream)");
-    if (h->layout_N == N && h->layout_T == T && h->layout_inv == h->inv) return AMX_OK;
+    if (h->layout_N == N && h->layout_T == T && h->layout_inv == h->inv && h->layout_gen == h->inventories[h->inv].generation)
+        return AMX_OK;
     build_tables(h, h->P1, h->col, h->width, h->ld_logits, h->out_unique, h->out_all);
     h->outputs.clear();
     int64_t off = 0;
@@ -826,6 +831,7 @@ static int compute_layout(amx_handle h, int N, int64_t L) {
     h->layout_N = N;
     h->layout_T = T;
     h->layout_inv = h->inv;
+    h->layout_gen = h->inventories[h->inv].generation;
     return AMX_OK;
 }
 
@@ -1332,7 +1338,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         }
     }
     { Timed t_(h, AMX_KC_OTHER); launch_logsoftmax_out(h->out_unique_dev, (int)h->out_unique.size(), (const float*)logits, h->ld_logits, N, T,
-                          (flags & AMX_FLAG_RAW_LOGITS) ? 0 : 1, d_out, s); }
+                          (const int*)d_frames, (flags & AMX_FLAG_RAW_LOGITS) ? 0 : 1, d_out, s); }
     HIPCHK(h, hipGetLastError());
     if (flags & AMX_FLAG_HOST_IO) {
         HIPCHK(h, hipMemcpyAsync(out, d_out, (size_t)total * 4, hipMemcpyDeviceToHost, s));

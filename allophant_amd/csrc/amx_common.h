@@ -294,7 +294,7 @@ struct OutDesc {
                       // (geometry-independent, so the device table only changes with the inventory)
 };
 void launch_logsoftmax_out(const OutDesc* descs_dev, int n_out, const float* logits, int64_t ld, int N, int T,
-                           int log_probs, float* out, hipStream_t s);
+                           const int* frame_len, int log_probs, float* out, hipStream_t s);
 void launch_greedy_ctc(const OutDesc* descs_dev, int n_out, const float* out, const int* frame_len, int N, int T,
                        int64_t* tokens, int64_t* timesteps, int* counts, float* scores, hipStream_t s);
 // the same decoder over one [N, T, C] emission tensor with element strides (stride_n, stride_t, 1)

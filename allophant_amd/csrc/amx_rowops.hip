@@ -543,15 +543,27 @@ __global__ __launch_bounds__(256) void time_attention_kernel(const float* __rest
 }
 
 // ----------------------------------------------------------------------------------------------------------------
-// per-head log-softmax (reference estimator.py:1041-1045), batch-major logits -> time-major [T,N,C] outputs
+// per-head log-softmax (reference estimator.py:1041-1045), batch-major logits -> time-major [T,N,C] outputs.
+// Frames t >= frame_len[n] are published as zeros: upstream leaves layout-dependent garbage there (padded queries run
+// through every layer), here the padded and the packed row layouts must hand consumers of whole [T, N, C] tensors the
+// same bytes (the contract: frames beyond `lengths` carry no information).
 // ----------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void logsoftmax_out_kernel(const OutDesc* __restrict__ descs, int n_out,
                                                              const float* __restrict__ logits, int64_t ld, int N, int T,
-                                                             int log_probs, float* __restrict__ out) {
+                                                             const int* __restrict__ frame_len, int log_probs,
+                                                             float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // row = n*T + t
     if (row >= (int64_t)N * T) return;
     const int n = (int)(row / T), t = (int)(row % T);
+    if (t >= frame_len[n]) {
+        for (int o = 0; o < n_out; ++o) {
+            const OutDesc d = descs[o];
+            float* dst = out + (int64_t)T * N * d.prefix + ((int64_t)t * N + n) * d.C;
+            for (int c = lane; c < d.C; c += 64) dst[c] = 0.f;
+        }
+        return;
+    }
     const float* src_row = logits + row * ld;
     // narrow outputs (the attribute classifiers: 4 classes each): one LANE per output, everything lane-local -- a wave
     // reduction per 4-class output (36 of them per frame) made this kernel 20x slower than its 11 MB of traffic
@@ -881,10 +893,10 @@ void launch_time_attention(int prec, const float* qkv, const int* frame_len, int
 }
 
 void launch_logsoftmax_out(const OutDesc* descs_dev, int n_out, const float* logits, int64_t ld, int N, int T,
-                           int log_probs, float* out, hipStream_t s) {
+                           const int* frame_len, int log_probs, float* out, hipStream_t s) {
     int64_t M = (int64_t)N * T;
     hipLaunchKernelGGL(logsoftmax_out_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, descs_dev, n_out, logits, ld,
-                       N, T, log_probs, out);
+                       N, T, frame_len, log_probs, out);
 }
 
 void launch_greedy_ctc(const OutDesc* descs_dev, int n_out, const float* out, const int* frame_len, int N, int T,

@@ -40,11 +40,22 @@ class Batch:
         return self
 
     def to(self, device, non_blocking: bool = False, copy: bool = False):
-        return self.__class__(
+        moved = self.__class__(
             self.audio_features.to(device, non_blocking=non_blocking, copy=copy),
             self.lengths.to(device, non_blocking=non_blocking, copy=copy),
             self.language_ids.to(device, non_blocking=non_blocking, copy=copy),
         )
+        slot = getattr(self, "_pinned_slot", None)
+        if slot is not None:
+            if moved.audio_features.device.type == "cuda" and non_blocking:
+                # an asynchronous copy out of a `batching.PinnedCollator` slot: the collator refills the slot only behind
+                # this event
+                event = torch.cuda.Event()
+                event.record(torch.cuda.current_stream(moved.audio_features.device))
+                slot[0].mark_in_flight(self, event)
+            elif moved.audio_features.data_ptr() == self.audio_features.data_ptr():
+                moved._pinned_slot = slot  # same storage (a no-op move): still the collator's slot
+        return moved
 
     def cuda(self, non_blocking: bool = False, copy: bool = False):
         return self.to("cuda", non_blocking, copy)

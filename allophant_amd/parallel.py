@@ -170,26 +170,65 @@ def gather_flat_predictions(local: Predictions, device: torch.device, dst: int =
 class DataParallelRunner:
     """The per-step data path of data-parallel prediction as ``bench.py --gpus N`` times it (BASELINE config 3): every rank
     predicts its shard, the log-probabilities go to rank ``dst`` in ONE flat gather per step (equal-shaped shards, e.g.
-    32 utterances over 2 / 4 / 8 ranks) or the general padded gather (ragged shards).  With ``overlap`` the gather of step k
-    stays in flight on the backend's stream under the forward pass of step k + 1 and is completed before step k + 2 is
-    enqueued; ``drain()`` completes the last one.  ``step`` returns, on ``dst``, the assembled global ``Predictions`` of the
-    most recently COMPLETED gather (the previous step when overlapping), ``None`` elsewhere / before the first completion."""
+    32 utterances over 2 / 4 / 8 ranks) or the general padded gather (ragged or empty shards).  With ``overlap`` the gather
+    of step k stays in flight on the backend's stream under the forward pass of step k + 1 and is completed before step
+    k + 2 is enqueued; ``drain()`` completes the last one.  ``step`` returns, on ``dst``, the assembled global
+    ``Predictions`` of the most recently COMPLETED gather (the previous step when overlapping), ``None`` elsewhere / before
+    the first completion.
+
+    ``flat=True`` is the fast path for shards of one common ``(N, L)`` geometry; every step first agrees on that with one
+    small ``all_reduce`` (a rank whose shard is empty or shaped differently would otherwise leave the others hanging in a
+    mismatched ``gather``) and falls back to the padded gather when the shards differ.  The padded gather needs
+    ``total_utterances`` and, because a rank with an empty shard (``local_batch=None``) has no local prediction to read
+    them from, ``outputs`` = the distinct outputs as (name, classes) in output order and ``aliases`` (see
+    ``unique_outputs``) -- or at least one earlier non-empty step on this rank to learn them from.  The agreement reads
+    two integers back per step, i.e. the host waits for the step it has just enqueued; a caller that has established equal
+    shards on the host already (``bench.py``: ``shard_bounds`` of equal-length utterances) passes ``verify_shapes=False``
+    and keeps the host running ahead of the GPU."""
 
     def __init__(self, predict: Callable[[Batch], Predictions], device: torch.device, dst: int = 0, group=None,
-                 overlap: bool = True, flat: bool = True, total_utterances: Optional[int] = None):
+                 overlap: bool = True, flat: bool = True, total_utterances: Optional[int] = None,
+                 outputs: Optional[List[Tuple[str, int]]] = None, aliases: Optional[Dict[str, str]] = None,
+                 verify_shapes: bool = True):
         self._predict, self._device, self._dst, self._group = predict, device, dst, group
+        self._verify = verify_shapes
         self._overlap, self._flat, self._total = overlap, flat, total_utterances
+        self._outputs, self._aliases = outputs, aliases
         self._pending: Optional[PendingGather] = None
         self.completed = 0  # gathers completed so far
+        if not flat and total_utterances is None:
+            raise ValueError("the padded gather (flat=False) needs total_utterances, the size of the global batch")
+
+    def _same_geometry(self, local: Optional[Predictions]) -> bool:
+        """True when every rank holds a flat block of one common size and utterance count (one tiny all_reduce)."""
+        size = -1 if local is None or local._flat is None else local._flat.numel()
+        count = -1 if local is None else len(local.lengths)
+        probe = torch.tensor([size, -size, count, -count], dtype=torch.int64, device=self._device)
+        dist.all_reduce(probe, op=dist.ReduceOp.MAX, group=self._group)
+        lo_size, lo_count = -int(probe[1]), -int(probe[3])
+        return lo_size >= 0 and lo_size == int(probe[0]) and lo_count == int(probe[2])
+
+    def _padded(self, local: Optional[Predictions]) -> Optional[Predictions]:
+        if local is not None and self._outputs is None:
+            self._outputs, self._aliases = unique_outputs(local)
+        if self._outputs is None:
+            raise ValueError("a rank with an empty shard needs `outputs` (and `aliases`): it has no local prediction to take "
+                             "the output names and widths from")
+        if self._total is None:
+            raise ValueError("shards of different shapes need the padded gather: pass total_utterances")
+        result = gather_predictions(local, self._outputs, self._total, self._device, dst=self._dst, group=self._group,
+                                    aliases=self._aliases)
+        self.completed += 1
+        return result
 
     def step(self, local_batch: Optional[Batch]) -> Optional[Predictions]:
         local = self._predict(local_batch) if local_batch is not None else None
         if not self._flat:
-            # ragged shards: synchronous padded gather (shapes differ per rank, agreed on inside)
-            unique, aliases = unique_outputs(local)
-            result = gather_predictions(local, unique, self._total, self._device, dst=self._dst, group=self._group, aliases=aliases)
-            self.completed += 1
-            return result
+            return self._padded(local)
+        if self._verify and not self._same_geometry(local):
+            # the flat gather cannot take this step: complete what is in flight (order on rank `dst`), then gather padded
+            self.drain()
+            return self._padded(local)
         handle = gather_flat_predictions(local, self._device, dst=self._dst, group=self._group, async_op=True)
         if not self._overlap:
             self.completed += 1

@@ -2,6 +2,7 @@
 """Benchmark of the Allophant acoustic-encoder forward path (``Estimator.predict``) on MI355X.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without WORLD_SIZE: starts its own N ranks, see `self_launch`)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -22,9 +23,12 @@ section "Measurement" defines every field).
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
 import statistics
+import subprocess
 import sys
 import time
 
@@ -42,7 +46,7 @@ MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/f16 MFMA peak, /opt/skills/guides/MI355X
 HBM_PEAK_GBS = 8000.0
 MEASURED_MFMA_CEILING_TFLOPS = 2100.0  # 16x16x32 f16, two waves per SIMD (profiles/r02_mfma_only_ceiling.log)
 MEASURED_STORE_CEILING_GBS = 5100.0  # best pure-store rate of tools/hbm_bw_probe.hip on an MI355X (profiles/r02_hbm_bw.log)
-TRAFFIC_FILES = ("r02_traffic.json", "r01_gemm_traffic.json")  # newest first; written by tools/collect_profiles.py
+TRAFFIC_FILES = ("r03_traffic.json", "r02_traffic.json")  # newest first; written by tools/collect_profiles.py
 
 
 def build_spec():
@@ -118,44 +122,139 @@ def work_model(spec, n, length, planes):
             "gemm_tile": tile, "attention": attention, "total": total, "frames_per_utt": T}
 
 
-def cpu_baseline(spec, state, tfi, n_sample, length):
+def physical_cores():
+    """(physical cores, logical CPUs) this process may run on: distinct (physical id, core id) pairs of /proc/cpuinfo among
+    the CPUs of the affinity mask (sockets x cores, SMT siblings counted once)."""
+    try:
+        allowed = os.sched_getaffinity(0)
+    except AttributeError:
+        allowed = set(range(os.cpu_count() or 1))
+    pairs, cpu, phys = set(), None, None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                key, _, val = line.partition(":")
+                key, val = key.strip(), val.strip()
+                if key == "processor":
+                    cpu, phys = int(val), None
+                elif key == "physical id":
+                    phys = val
+                elif key == "core id" and cpu in allowed:
+                    pairs.add((phys, val))
+    except OSError:
+        pass
+    return (len(pairs) or len(allowed)), len(allowed)
+
+
+def cpu_baseline(spec, state, tfi, audio, lengths):
     """Times the CPU oracle (oracle/allophant_oracle.py: the restatement pinned against the reference) on the host cores
-    of this box on a bounded sample of the same workload: one warm-up run of the SAME batch, then the median of three timed
-    runs.  Reported baseline, not the target."""
+    of this box on a bounded sample of the same workload (the first utterances of the benchmark batch; SURVEY.md section
+    8d).  The thread count is chosen by a sweep on a two-utterance slice (physical cores, a half, a quarter, and 8 -- the
+    survey's container figure was taken on 8 threads): fp32 GEMMs of 499-row utterances stop scaling long before a 2-socket
+    box runs out of cores, and oversubscribing them is slower than a few cores.  Then one warm-up and two timed runs of the
+    sample at the best count.  Reported baseline, not the target.  Returns (record, oracle outputs of the sample, frame
+    lengths) -- the outputs double as the parity spot check of the timed path."""
     from oracle import allophant_oracle as O
 
-    cores = max(1, (os.cpu_count() or 2) // 2)
-    torch.set_num_threads(cores)
-    audio, lengths = synthetic.make_audio(n_sample, length, seed=1234)
+    cores, logical = physical_cores()
     offsets = synthetic.category_offsets(spec)
-    O.predict(audio, lengths, state, spec, tfi, offsets, True)  # warm-up: thread pool, allocator, same shapes
-    times = []
-    frames = 0
-    for _ in range(3):
+    candidates = sorted({max(1, cores), max(1, cores // 2), max(1, cores // 4), min(8, max(1, cores))}, reverse=True)
+    sweep = {}
+    probe_a, probe_l = audio[:2].contiguous(), lengths[:2].contiguous()
+    for threads in candidates:
+        torch.set_num_threads(threads)
+        O.predict(probe_a, probe_l, state, spec, tfi, offsets, True)  # warm-up of the pool at this size
+        t0 = time.perf_counter()
+        _, flen = O.predict(probe_a, probe_l, state, spec, tfi, offsets, True)
+        sweep[threads] = int(flen.sum()) / (time.perf_counter() - t0)
+    best = max(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    times, out, flen = [], None, None
+    O.predict(audio, lengths, state, spec, tfi, offsets, True)
+    for _ in range(2):
         t0 = time.perf_counter()
         out, flen = O.predict(audio, lengths, state, spec, tfi, offsets, True)
         times.append(time.perf_counter() - t0)
-        frames = int(flen.sum())
+    frames = int(flen.sum())
     med = statistics.median(times)
-    return {"value": frames / med, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{n_sample} x {length / 16000:.0f} s utterances of the same synthetic workload, fp32 torch CPU oracle, one "
-                      f"warm-up run of the same batch + median of {len(times)} timed runs ({med:.2f} s; all: "
-                      + ", ".join(f"{t:.2f}" for t in times) + " s)"}
+    record = {"value": frames / med, "unit": "frames/s", "cores": best, "kind": "port",
+              "physical_cores": cores, "logical_cpus": logical,
+              "thread_sweep_frames_per_s": {str(k): round(v, 1) for k, v in sweep.items()},
+              "sample": f"the first {len(lengths)} x {audio.shape[1] / 16000:.0f} s utterances of the benchmark batch, fp32 torch CPU "
+                        f"oracle on {best} threads (best of a sweep over {candidates} on a 2-utterance slice; {cores} physical cores, "
+                        f"{logical} logical CPUs), one warm-up run of the same sample + median of {len(times)} timed runs "
+                        f"({med:.2f} s; all: " + ", ".join(f"{t:.2f}" for t in times) + " s)"}
+    return record, out, flen
+
+
+def kernel_source_hash():
+    """Identifies the kernels a measurement belongs to: sha256 over the HIP sources of liballophant_amx (names + bytes)."""
+    digest = hashlib.sha256()
+    csrc = os.path.join(ROOT, "allophant_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".inc", ".h")):
+            digest.update(name.encode())
+            with open(os.path.join(csrc, name), "rb") as f:
+                digest.update(f.read())
+    return digest.hexdigest()[:16]
 
 
 def load_traffic(precision):
     """Measured HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/, collected with
     tools/profile_bench.sh exactly as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in separate passes,
-    FETCH_SIZE doubled).  NOT measured in this run: the file it came from is reported beside it."""
+    FETCH_SIZE doubled).  NOT measured in this run: the file carries the hash of the kernel sources it was measured on
+    (tools/collect_profiles.py) and is used only when that equals the hash of the sources in this tree -- a kernel change
+    nulls `traffic` until the PMC passes are repeated.  Returns (data or None, description of the source)."""
+    current = kernel_source_hash()
+    stale = None
     for name in TRAFFIC_FILES:
         path = os.path.join(ROOT, "profiles", name)
         try:
             with open(path) as f:
-                data = json.load(f)[precision]
-            return data, "profiles/" + name
+                blob = json.load(f)
+            data = blob[precision]
         except Exception:
             continue
-    return None, None
+        measured_on = blob.get("kernel_source_hash")
+        if measured_on == current:
+            return data, (f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on kernel sources "
+                          f"{current}, FETCH_SIZE doubled per MI355X_MICROARCH.md; not a live counter)")
+        stale = stale or f"profiles/{name} was measured on kernel sources {measured_on}, this tree is {current}: traffic not reported"
+    return None, stale
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(argv, gpus):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: this process has not touched the GPU (no
+    HIP call, no torch.cuda.is_available()), so it starts N fresh ranks -- `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>` on this same file, as a CHILD process, never a re-exec
+    -- relays rank 0's single JSON line on stdout and exits with the children's status.  AMX_BENCH_CHILD_SCRIPT (tests) names
+    another script for the ranks to run."""
+    script = os.environ.get("AMX_BENCH_CHILD_SCRIPT") or os.path.abspath(__file__)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), script] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or gpus) // gpus)))
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    lines = [ln for ln in proc.stdout.decode(errors="replace").splitlines() if ln.strip()]
+    json_lines = [ln for ln in lines if ln.lstrip().startswith("{")]
+    for ln in lines:
+        if ln not in json_lines:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0:
+        print(f"bench.py: a rank failed (torch.distributed.run exited with {proc.returncode})", file=sys.stderr)
+        return proc.returncode or 1
+    if len(json_lines) != 1:
+        print(f"bench.py: expected one JSON line from rank 0, got {len(json_lines)}", file=sys.stderr)
+        return 1
+    print(json_lines[0], flush=True)
+    return 0
 
 
 def main():
@@ -170,13 +269,17 @@ def main():
     ap.add_argument("--also", default="bf16", choices=["", "f16x3", "bf16x3", "f16", "bf16"],
                     help="second precision mode reported under throughput_mode (N=1 only; empty string to skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=4)
+    ap.add_argument("--cpu-sample", type=int, default=8, help="utterances of the batch the CPU baseline (and spot check) runs on")
+    ap.add_argument("--no-spot-check", action="store_true", help="skip the oracle spot check of the timed path")
     ap.add_argument("--decoded-gather", action="store_true",
                     help="N > 1: also time the step that gathers greedy CTC alignments of the phoneme output instead of log-probs")
     ap.add_argument("--no-ragged", action="store_true", help="N = 1: skip the informational ragged-batch leg")
     ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the weak-scaling leg (32 x 10 s per GPU)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("AMX_BENCH_FORCE_LAUNCH") == "1"):
+        # nothing above touched the GPU: this process only starts the ranks and relays rank 0's line
+        raise SystemExit(self_launch(sys.argv[1:], args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -212,7 +315,8 @@ def main():
         synchronize, max over ranks; then a second pass of K steps with HIP events around every launch for the per-kernel
         numbers.  `batch` is this rank's device-resident shard."""
         est = Estimator(spec, state, device, precision)
-        runner = parallel.DataParallelRunner(lambda b: est.predict(b, tfi, True), device, dst=0) if use_dist else None
+        # equal shards are established on the host below (shard_bounds of equal-length utterances): no per-step agreement
+        runner = parallel.DataParallelRunner(lambda b: est.predict(b, tfi, True), device, dst=0, verify_shapes=False) if use_dist else None
 
         def step(timing=False):
             if runner is None:
@@ -260,7 +364,7 @@ def main():
         issue = 3 if planes == 2 else 1
         w = work_model(spec, n_local, length, planes)
         traffic, traffic_source = load_traffic(precision)
-        traffic = traffic or {}
+        traffic = traffic or {}  # {} when no PMC pass of THESE kernel sources is committed: every traffic field is null
 
         def rate(flops, cls):
             ms = timing[cls][0]
@@ -285,8 +389,7 @@ def main():
             "unit": "TFLOP/s",
             "frac": achieved / MFMA_PEAK_TFLOPS if achieved else None,
             "traffic": traffic.get("hbm_bytes_per_launch"),
-            "traffic_source": (traffic_source + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this "
-                               "command, FETCH_SIZE doubled per MI355X_MICROARCH.md; not a live counter)") if traffic_source else None,
+            "traffic_source": traffic_source,
             "flops_per_launch": w["gemm_pp"] / max(1, w["gemm_pp_launches"]),
             "algorithmic_bytes_per_launch": w["gemm_pp_bytes"] / max(1, w["gemm_pp_launches"]),
             "avg_launch_ms": gemm_ms / gemm_launches if gemm_launches else None,
@@ -304,10 +407,11 @@ def main():
                     "bound": "hbm", "algorithmic_bytes": w["conv0_bytes"], "ms": conv0_ms, "achieved": conv0_gbs,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": conv0_gbs / HBM_PEAK_GBS if conv0_gbs else None,
                     "traffic": traffic.get("conv0_hbm_bytes_per_launch"),
-                    # 99 % of this kernel's bytes are stores; a pure 16-byte store kernel reaches 3.9-5.1 TB/s on this part
-                    # (tools/hbm_bw_probe.hip, profiles/r02_hbm_bw.log; reads 6.3 TB/s), so the store ceiling is the nearer bound
-                    "store_ceiling": MEASURED_STORE_CEILING_GBS,
-                    "frac_of_store_ceiling": conv0_gbs / MEASURED_STORE_CEILING_GBS if conv0_gbs else None,
+                    # 99 % of this kernel's bytes are stores.  For scale only: what this repo's own pure-store probe reaches
+                    # (tools/hbm_bw_probe.hip; the microarch guide records 6.0-6.2 TB/s for plain stores) -- `frac` above, against
+                    # the 8 TB/s peak, is the roofline figure
+                    "own_store_probe_gbs": MEASURED_STORE_CEILING_GBS,
+                    "frac_of_own_probe": conv0_gbs / MEASURED_STORE_CEILING_GBS if conv0_gbs else None,
                 },
                 "conv1_5": {
                     "kernel": "gemm_ln_kernel<T16, planes>: 128x512 row-complete implicit GEMM + LayerNorm + GELU",
@@ -477,10 +581,46 @@ def main():
         except Exception as exc:  # informational leg: never costs the headline
             result["ragged_batch"] = {"error": repr(exc)}
     if rank == 0:
+        # CPU baseline on the first `cpu_sample` utterances of the benchmark batch (N = 1 only), and -- AFTER every timed
+        # region -- the parity spot check of the path that was timed: the outputs of one more `predict` of the benchmark batch
+        # against the CPU oracle on those utterances (each result is independent of the batch it sits in: SURVEY.md Appendix
+        # A), log-probs on valid frames.  Without the baseline leg the check runs the oracle on one utterance alone.
+        oracle_out = oracle_len = None
+        n_check = max(1, min(args.cpu_sample, n_global)) if world == 1 else 1
         if not args.no_cpu_baseline and world == 1:
-            result["cpu_baseline"] = cpu_baseline(spec, state, tfi, args.cpu_sample, length)
+            result["cpu_baseline"], oracle_out, oracle_len = cpu_baseline(spec, state, tfi, audio[:n_check].contiguous(),
+                                                                          lengths[:n_check].contiguous())
         else:
             result["cpu_baseline"] = None
+        if not args.no_spot_check:
+            try:
+                if oracle_out is None:
+                    from oracle import allophant_oracle as O
+
+                    n_check = 1
+                    oracle_out, oracle_len = O.predict(audio[:1].contiguous(), lengths[:1].contiguous(), state, spec, tfi,
+                                                       synthetic.category_offsets(spec), True)
+                est = Estimator(spec, state, device, args.precision)
+                pred = est.predict(local, tfi, True)  # rank 0's shard starts at utterance 0 of the global batch
+                n_check = min(n_check, n_local)
+                worst, where = 0.0, None
+                for name, expected in oracle_out.items():
+                    got = pred.outputs[name][:, :n_check].cpu()
+                    for i in range(n_check):
+                        t_i = int(oracle_len[i])
+                        err = (got[:t_i, i] - expected[:t_i, i]).abs().max().item()
+                        if err > worst:
+                            worst, where = err, (i, name)
+                est.close()
+                result["parity_spot_check"] = {
+                    "max_abs": worst, "utterance": where[0] if where else None, "output": where[1] if where else None,
+                    "utterances_checked": n_check, "outputs_checked": len(oracle_out), "gate": 1e-3 if args.precision.endswith("x3") else None,
+                    "passed": bool(worst < 1e-3) if args.precision.endswith("x3") else None,
+                    "against": "CPU oracle (oracle/allophant_oracle.py) on the same utterances, log-probabilities of valid frames; "
+                               "run after the timed region on the same handle configuration and batch",
+                }
+            except Exception as exc:
+                result["parity_spot_check"] = {"error": repr(exc)}
     sys.stdout.flush()
     os.dup2(saved_stdout, 1)
     os.close(saved_stdout)

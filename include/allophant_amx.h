@@ -52,8 +52,6 @@ extern "C" {
 #define AMX_FLAG_PADDED 16u      /* L may exceed max(lengths): the call is one slice of a larger batch padded to L (the
                                     reference itself requires L == max(lengths), utils.py:62-63) */
 #define AMX_FLAG_NO_PACK 32u     /* keep the padded [N, T] row layout through the encoder layers even for a ragged batch (the
-                                    default runs them on the valid frames only; results on valid frames are identical) */
-#define AMX_FLAG_NO_PACK 32u     /* keep the padded [N, T] row layout through the encoder layers even for a ragged batch (the
                                   * default runs them on the valid frames only; results on valid frames are identical) */
 
 /* kernel classes reported by amx_timing_fetch */

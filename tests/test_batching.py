@@ -95,3 +95,24 @@ def test_pinned_collator_equals_collate():
         ref = B.collate(audio, [1, 1, 2])
         assert torch.equal(got.audio_features, ref.audio_features) and torch.equal(got.lengths, ref.lengths)
         audio = audio[::-1]
+
+
+@pytest.mark.gpu
+def test_pinned_collator_slot_travels_with_asynchronous_copies():
+    """A slot is refilled only behind the copy that read it, whoever issued the copy: ``Batch.to(device, non_blocking=True)``
+    reports its event to the collator; an over-long batch takes a one-off buffer and does not skip a ring slot."""
+    if not torch.cuda.is_available():
+        pytest.skip("pinned host memory needs the HIP runtime")
+    ring = B.PinnedCollator(32, depth=2)
+    first = ring([torch.full((8,), 1.0), torch.full((4,), 2.0)])
+    assert first._pinned_slot == (ring, 0)
+    dev = first.to("cuda:0", non_blocking=True)
+    assert ring._events[0] is not None  # the asynchronous copy handed its event over
+    big = ring([torch.zeros(40)])  # does not fit a slot: one-off pinned buffer ...
+    assert getattr(big, "_pinned_slot", None) is None and big.audio_features.is_pinned()
+    second = ring([torch.full((6,), 3.0)])
+    assert second._pinned_slot == (ring, 1)  # ... and the ring did not advance past slot 1
+    third = ring([torch.full((8,), 4.0)])   # back on slot 0: waits for the event of `first`'s copy, then refills
+    assert third._pinned_slot == (ring, 0) and ring._events[0] is None
+    torch.cuda.synchronize()
+    assert dev.audio_features.cpu().tolist() == [[1.0] * 8, [2.0] * 4 + [0.0] * 4]

@@ -256,3 +256,67 @@ def test_two_rank_gather_of_decoded_alignments(tmp_path):
                 assert g[0].tokens.dtype == torch.int64 and g[0].tokens.tolist() == w[0].tokens.tolist()
                 assert g[0].timesteps.tolist() == w[0].timesteps.tolist()
                 assert g[0].score == w[0].score
+
+
+# ---- DataParallelRunner with an empty shard and with shards of different shapes (round-2 advisor finding) ----
+def _uneven_runner_worker(rank, world, port, result_path):
+    from oracle import allophant_oracle as O
+    from allophant_amd.parallel import DataParallelRunner
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    spec, state, _, _, tfi = _setup()
+    offsets = synthetic.category_offsets(spec)
+
+    def predict(batch):
+        out, flen = O.predict(batch.audio_features, batch.lengths, state, spec, tfi, offsets)
+        return _flat_predictions(out, flen)
+
+    names = [("syllabic", 4), ("long", 4), ("phoneme", 7)]
+    results = []
+    # (utterances, ragged): 1 utterance on 2 ranks = an empty shard on rank 1; 3 ragged = shards of different (N, L);
+    # 4 equal = the flat fast path again, after the fallbacks
+    for step, (total, ragged) in enumerate([(1, False), (3, True), (4, False)]):
+        runner = DataParallelRunner(predict, torch.device("cpu"), dst=0, total_utterances=total, outputs=names,
+                                    aliases={"phone": "phoneme"})
+        audio, lengths = synthetic.make_audio(total, 2400, seed=70 + step, ragged=ragged)
+        shard = shard_batch(Batch(audio, lengths, torch.zeros(total, dtype=torch.long)), rank, world)
+        if total == 1 and rank == 1:
+            assert shard is None
+        got = runner.step(shard)
+        got = got if got is not None else runner.drain()
+        results.append(None if got is None else {"outputs": dict(got.outputs), "lengths": got.lengths.cpu()})
+    if rank == 0:
+        assert all(r is not None for r in results)
+        torch.save(results, result_path)
+    else:
+        assert all(r is None for r in results)
+    # the padded gather without the size of the global batch is refused at construction, not in the middle of a collective
+    try:
+        DataParallelRunner(predict, torch.device("cpu"), flat=False)
+        raise AssertionError("flat=False without total_utterances must be refused")
+    except ValueError:
+        pass
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_runner_with_empty_and_uneven_shards(tmp_path):
+    from oracle import allophant_oracle as O
+
+    result_path = str(tmp_path / "uneven.pt")
+    mp.spawn(_uneven_runner_worker, args=(2, _free_port(), result_path), nprocs=2, join=True)
+    got = torch.load(result_path)
+    spec, state, _, _, tfi = _setup()
+    for step, (total, ragged) in enumerate([(1, False), (3, True), (4, False)]):
+        audio, lengths = synthetic.make_audio(total, 2400, seed=70 + step, ragged=ragged)
+        ref, ref_len = O.predict(audio, lengths, state, spec, tfi, synthetic.category_offsets(spec))
+        g = got[step]
+        assert list(g["outputs"]) == list(ref), step
+        assert g["lengths"].tolist() == ref_len.tolist(), step
+        for name in ref:
+            valid = (torch.arange(ref[name].shape[0]).unsqueeze(1) < ref_len.unsqueeze(0)).unsqueeze(-1)
+            assert g["outputs"][name].shape == ref[name].shape, (step, name)
+            assert ((g["outputs"][name] - ref[name]).abs() * valid).max().item() < 1e-4, (step, name)

@@ -200,16 +200,18 @@ def test_utterance_shorter_than_the_receptive_field_is_refused(amd):
     est.close()
 
 
-def test_batches_beyond_the_32_bit_plane_offsets(amd):
-    """24 x 60 s in the two-plane mode: the conv-0 output plane would be 4.7 GB, past the 32-bit plane offsets of the
-    kernels.  The C ABI refuses such a call (AMX_EINVAL) and reports the limit; the facade runs the batch as slices and
-    the results equal solo runs of the utterances."""
+@pytest.mark.parametrize("precision,tolerance", [("f16x3", 2e-4), ("f16", 6e-2)])
+def test_batches_beyond_the_32_bit_plane_offsets(amd, precision, tolerance):
+    """24 x 60 s: one conv-0 output plane would be 4.7 GB, past the 32-bit plane offsets of the kernels -- in the two-plane
+    mode and in the single-plane mode alike (the same limit applies to both).  The C ABI refuses such a call (AMX_EINVAL)
+    and reports the limit; the facade runs the batch as slices and the results equal solo runs of the utterances (f16: the
+    batch and the solo run take differently tiled kernels, so they agree within that mode's measured error)."""
     from allophant_amd import lib
 
     spec = S.multitask_spec(S.xlsr_300m_encoder(), allophone_layer=True)
     spec["shared_phones"] = 80
     state = synthetic.make_state_dict(spec, seed=0)
-    est = amd.Estimator(spec, state, "cuda:0", "f16x3")
+    est = amd.Estimator(spec, state, "cuda:0", precision)
     tfi = synthetic.make_inventory(spec, 27, seed=0)
     n, length = 24, 960000
     handle = lib.load()
@@ -230,7 +232,7 @@ def test_batches_beyond_the_32_bit_plane_offsets(amd):
         n_i, t_i = int(lengths[i]), int(pred.lengths[i])
         solo = est.predict(amd.Batch(dev[i:i + 1, :n_i].contiguous(), lengths[i:i + 1], torch.zeros(1, dtype=torch.long)), tfi)
         for k in ("phoneme", "stress", "click"):
-            assert (pred.outputs[k][:t_i, i] - solo.outputs[k][:t_i, 0]).abs().max().item() < 2e-4, (i, k)
+            assert (pred.outputs[k][:t_i, i] - solo.outputs[k][:t_i, 0]).abs().max().item() < tolerance, (i, k)
     decoded = est.greedy_decode(pred)
     assert len(decoded["phoneme"]) == n
     est.close()
@@ -256,8 +258,7 @@ def test_prefetcher_matches_the_plain_loop(amd):
         b = batching.collate([corpus[i] for i in indices])
         plain.append(est.predict(b.to("cuda:0"), tfi)._flat.clone())
     collator = batching.PinnedCollator(max_samples=120000, depth=2)
-    prefetcher = batching.Prefetcher(index_batches, torch.device("cuda:0"), fetch=lambda ix: collator([corpus[i] for i in ix]),
-                                     collator=collator)
+    prefetcher = batching.Prefetcher(index_batches, torch.device("cuda:0"), fetch=lambda ix: collator([corpus[i] for i in ix]))
     assert prefetcher.copy_stream != torch.cuda.current_stream()
     count = 0
     for batch, expected in zip(prefetcher, plain):

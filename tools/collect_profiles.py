@@ -16,9 +16,12 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 round_tag = sys.argv[1]
 traffic = {}
+hashes = set()
 for arg in sys.argv[2:]:
     precision, directory = arg.split(":")
     src = os.path.join(ROOT, "gpurun_out", directory)
+    with open(os.path.join(src, "kernel_source_hash.txt")) as f:  # written on the box by tools/profile_bench.sh
+        hashes.add(f.read().strip())
     dst = os.path.join(ROOT, "profiles", f"{round_tag}_{precision}")
     shutil.copy(os.path.join(src, "kernel_stats.csv"), dst + "_kernel_stats.csv")
     shutil.copy(os.path.join(src, "bench_traced.json"), dst + "_bench_under_rocprof.json")
@@ -82,4 +85,7 @@ for arg in sys.argv[2:]:
         steps = max(1, ln[0]["FETCH_SIZE"]["dispatches"] // 5)  # 5 launches (conv layers 1-5) per step
         traffic[precision]["gemm_ln_hbm_bytes_per_step"] = (2.0 * f + w) * 1024.0 / steps
     print(precision, {k: round(v, 1) if isinstance(v, float) else v for k, v in traffic[precision].items() if k != "correction"})
+if len(hashes) != 1:
+    raise SystemExit(f"the profile directories were measured on different kernel sources: {sorted(hashes)}")
+traffic["kernel_source_hash"] = hashes.pop()
 json.dump(traffic, open(os.path.join(ROOT, "profiles", f"{round_tag}_traffic.json"), "w"), indent=1)

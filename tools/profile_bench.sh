@@ -6,6 +6,8 @@ TAG=${1:-run}; shift || true
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
+# the kernel sources these measurements belong to (bench.py nulls `roofline.traffic` when the tree has moved on)
+(cd "$ROOT" && python3 -c "import bench; print(bench.kernel_source_hash())") > "$OUT/kernel_source_hash.txt"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-ragged --also "" "$@" > "$OUT/bench_traced.json" 2> "$OUT/trace.err"
 for C in FETCH_SIZE WRITE_SIZE; do
