@@ -75,9 +75,21 @@ def _check(number, spec, state, tfi, audio, lengths, pred, picks, column_of=None
             worst = max(worst, (pred.outputs[k][:t_i, column].cpu() - ref[k][:t_i, 0]).abs().max().item())
         if alignments:
             for k in ("phoneme", "syllabic", "click"):
-                (tokens, timesteps, _), = O.greedy_ctc(ref[k].transpose(0, 1).contiguous(), ref_len)
-                (mine, mine_t, _), = O.greedy_ctc(pred.outputs[k][:, column:column + 1].cpu().transpose(0, 1).contiguous(), ref_len)
-                assert torch.equal(mine, tokens) and torch.equal(mine_t, timesteps), (i, k)
+                # greedy CTC is a per-frame argmax: it can only be required to agree where the reference's own margin between
+                # its two best classes exceeds the log-prob error (random weights give near-uniform 201-class distributions
+                # over 2 999 frames: near-ties exist).  Frames whose argmax differs must be such ties; without any, the
+                # alignments (tokens and timesteps) must be equal.
+                theirs, mine = ref[k][:t_i, 0], pred.outputs[k][:t_i, column].cpu()
+                a_ref, a_mine = theirs.argmax(-1), mine.argmax(-1)
+                differing = (a_ref != a_mine).nonzero().flatten().tolist()
+                for f in differing:
+                    margin = (theirs[f, a_ref[f]] - theirs[f, a_mine[f]]).item()
+                    assert margin < 2 * tolerance, (i, k, f, margin)
+                assert len(differing) <= max(1, t_i // 500), (i, k, differing)
+                if not differing:
+                    (tokens, timesteps, _), = O.greedy_ctc(ref[k].transpose(0, 1).contiguous(), ref_len)
+                    (got, got_t, _), = O.greedy_ctc(pred.outputs[k][:, column:column + 1].cpu().transpose(0, 1).contiguous(), ref_len)
+                    assert torch.equal(got, tokens) and torch.equal(got_t, timesteps), (i, k)
     assert worst < tolerance, worst
     return worst
 
