@@ -240,6 +240,32 @@ int main(int argc, char** argv) {
         return 0;
     }
 #endif
+    if (argc > 6 && !strcmp(argv[1], "soak")) {
+        // sustained load for tools/power_probe.sh: gemm_bench soak <prec> <M> <N> <K> <seconds>  (FFN1-like: GELU -> planes)
+        const int prec = atoi(argv[2]), M = atoi(argv[3]), N = atoi(argv[4]), K = atoi(argv[5]);
+        const double seconds = atof(argv[6]);
+        const int NT = prec_planes(prec);
+        size_t a_el = (size_t)M * K, w_el = (size_t)N * K, o_el = (size_t)M * N;
+        void *A, *W, *outp; float* bias;
+        CK(hipMalloc(&A, a_el * 2 * NT)); CK(hipMalloc(&W, w_el * 2 * NT)); CK(hipMalloc(&bias, N * 4)); CK(hipMalloc(&outp, o_el * 2 * NT));
+        fill16(A, a_el, 1, prec, false); fill16(W, w_el, 2, prec, false);
+        if (NT > 1) { fill16((char*)A + a_el * 2, a_el, 3, prec, true); fill16((char*)W + w_el * 2, w_el, 4, prec, true); }
+        fill32(bias, N, 5, 0.5f);
+        GemmParams g{};
+        g.A = A; g.a_plane = a_el; g.lda = K; g.rows_per_batch = M; g.W = W; g.w_plane = w_el; g.ldw = K; g.M = M; g.N = N; g.K = K;
+        g.scale = 1.f; g.bias = bias; g.act = 1; g.out_p = outp; g.out_plane = o_el; g.ldp = N;
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        double total_ms = 0; long launches = 0;
+        while (total_ms < seconds * 1e3) {
+            CK(hipEventRecord(e0, 0));
+            for (int i = 0; i < 200; ++i) launch_gemm(prec, g, 0);
+            CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            total_ms += ms; launches += 200;
+            printf("SOAK %.1f us per launch (200 launches)\n", ms * 1e3 / 200); fflush(stdout);
+        }
+        return 0;
+    }
     const bool check = argc < 2 || !strcmp(argv[1], "check");
     const bool timing = argc < 2 || !strcmp(argv[1], "time");
     if (argc > 5 && !strcmp(argv[1], "one")) {
