@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <initializer_list>
 #include <map>
 #include <cstdlib>
 #include <string>
@@ -22,6 +23,7 @@ struct Layer {
     float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
     void *wqkv, *wo, *w1, *w2;
     float *bqkv, *bo, *b1, *b2;
+    float r_qkv = 1.f, r_o = 1.f, r_1 = 1.f, r_2 = 1.f;  // 1 / (power of two the packed planes were multiplied by)
 };
 
 // One GEMM (or GEMM pair for the composition head) of the hierarchical projection
@@ -43,6 +45,7 @@ struct HeadStep {
     int Cpad = 0;               // rows rounded up to 8 (K of the in_proj / out_proj products)
     float *tl_g = nullptr, *tl_b = nullptr, *tl_bin = nullptr, *tl_bout = nullptr, *tl_pe = nullptr;
     void *tl_win = nullptr, *tl_wout = nullptr;
+    float r_w = 1.f, r_tin = 1.f, r_tout = 1.f;  // reciprocal pack scales of W, tl_win, tl_wout
 };
 
 }  // namespace
@@ -63,6 +66,14 @@ struct amx_handle_s {
     float* conv_g[AMX_MAX_CONV] = {};
     float* conv_be[AMX_MAX_CONV] = {};
     void* conv_w[AMX_MAX_CONV] = {};
+    // Range of the 16-bit planes: every weight tensor is packed times a power of two that puts its largest element into
+    // [4096, 8192) (exact, so results do not change) and the product's epilogue multiplies by the reciprocal kept here.  An
+    // fp16 lo plane only carries its 11 bits while it is a normal number (|w| >= 0.25) and the hi plane underflows below
+    // 6e-5: with unscaled planes the accuracy of the split modes would depend on the magnitude of the checkpoint's weights.
+    float conv_r[AMX_MAX_CONV] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+    float fp_r = 1.f, pos_r = 1.f;
+    std::vector<float> emb_host;  // composition embedding table (host copy: scale of a composed inventory matrix)
+    int* nonfinite = nullptr;     // device counter of valid frames with non-finite logits in the last forward pass
     float *fp_g = nullptr, *fp_b = nullptr, *fp_bias = nullptr;
     void* fp_w = nullptr;
     void* pos_w = nullptr;
@@ -82,6 +93,7 @@ struct amx_handle_s {
     struct Inventory {
         std::vector<int64_t> key;  // phones, features, tfi..., offsets...
         int P1 = 0;                // phones + blank
+        float r_composed = 1.f;    // reciprocal pack scale of composed_w
         void* composed_w = nullptr;
         float* composed_f32 = nullptr;
         int64_t* idx_dev = nullptr;
@@ -94,6 +106,7 @@ struct amx_handle_s {
     int inv = -1;  // current entry, -1 = composition model without an inventory yet
     uint64_t inv_clock = 0;
     int P1 = 0;    // of the current inventory
+    float r_composed = 1.f;
     void* composed_w = nullptr;
     float* composed_f32 = nullptr;
 
@@ -293,6 +306,27 @@ static int pack_linear(amx_handle h, const TensorMap& tm, const std::string& key
     return AMX_OK;
 }
 
+// power of two that puts the largest |w * pre| of the listed tensors into [4096, 8192); 1 for empty / zero / non-finite data
+static bool pack_scale_off() {  // AMX_NO_PACK_SCALE=1: developer A/B switch (unscaled planes, as before round 3)
+    static const bool off = getenv("AMX_NO_PACK_SCALE") && atoi(getenv("AMX_NO_PACK_SCALE")) != 0;
+    return off;
+}
+static float pow2_for(float m) {
+    if (pack_scale_off() || !(m > 0.f) || !std::isfinite(m)) return 1.f;
+    return std::ldexp(1.f, 12 - std::ilogb(m));
+}
+static float pack_scale(std::initializer_list<std::pair<const amx_tensor*, float>> tensors) {
+    float m = 0.f;
+    for (auto& tp : tensors) {
+        if (!tp.first) continue;
+        const float* d = tp.first->data;
+        float mt = 0.f;
+        for (int64_t i = 0; i < tp.first->numel; ++i) mt = std::max(mt, std::fabs(d[i]));
+        m = std::max(m, mt * std::fabs(tp.second));
+    }
+    return pow2_for(m);
+}
+
 static void* alloc_planes(amx_handle h, int64_t elems_per_plane) {
     return dev_alloc(h, (size_t)elems_per_plane * 2 * h->NT);
 }
@@ -401,7 +435,9 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
                 h->conv_w[i] = alloc_planes(h, plane);
                 if (!h->conv_w[i]) { h->err = "device allocation failed"; return bail(AMX_ENOMEM); }
                 if (hipMemcpy(staging, t->data, (size_t)t->numel * 4, hipMemcpyHostToDevice) != hipSuccess) { h->err = "H2D failed"; return bail(AMX_EHIP); }
-                launch_pack_conv_w(h->prec, staging, C, c_in, k, h->conv_w[i], plane, 0);
+                const float ps = pack_scale({{t, 1.f}});
+                h->conv_r[i] = 1.f / ps;
+                launch_pack_conv_w(h->prec, staging, C, c_in, k, ps, h->conv_w[i], plane, 0);
                 if (hipDeviceSynchronize() != hipSuccess) { h->err = "pack_conv_w failed"; return bail(AMX_EHIP); }
             }
             c_in = C;
@@ -415,7 +451,9 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
         TRY(upload_f32(h, tm, p + "projection.bias", D, &h->fp_bias));
         h->fp_w = alloc_planes(h, (int64_t)D * C);
         if (!h->fp_w) { h->err = "device allocation failed"; return bail(AMX_ENOMEM); }
-        TRY(pack_linear(h, tm, p + "projection.weight", D, C, 1.f, h->fp_w, (int64_t)D * C, C, 0, C, staging));
+        const float ps = pack_scale({{tm.get(p + "projection.weight"), 1.f}});
+        h->fp_r = 1.f / ps;
+        TRY(pack_linear(h, tm, p + "projection.weight", D, C, ps, h->fp_w, (int64_t)D * C, C, 0, C, staging));
     }
     // ---- positional conv (weight-norm folded) ----
     {
@@ -434,7 +472,24 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
         int64_t plane = (int64_t)D * cg * k;
         h->pos_w = alloc_planes(h, plane);
         if (!h->pos_w) { h->err = "device allocation failed"; return bail(AMX_ENOMEM); }
-        launch_pack_posconv_w(h->prec, gd, staging, D, cg, k, gd + k, h->pos_w, plane, 0);
+        float ps = 1.f;
+        {   // largest folded weight |v * g[tap] / ||v[:, :, tap]|||, on the host (the device folds them while packing)
+            std::vector<double> sq(k, 0.0);
+            std::vector<float> mx(k, 0.f);
+            const int64_t rows = (int64_t)D * cg;
+            for (int64_t r = 0; r < rows; ++r)
+                for (int tap = 0; tap < k; ++tap) {
+                    const float x = v->data[r * k + tap];
+                    sq[tap] += (double)x * x;
+                    mx[tap] = std::max(mx[tap], std::fabs(x));
+                }
+            float m = 0.f;
+            for (int tap = 0; tap < k; ++tap)
+                if (sq[tap] > 0.0) m = std::max(m, (float)(mx[tap] * std::fabs(g->data[tap]) / std::sqrt(sq[tap])));
+            ps = pow2_for(m);
+        }
+        h->pos_r = 1.f / ps;
+        launch_pack_posconv_w(h->prec, gd, staging, D, cg, k, ps, gd + k, h->pos_w, plane, 0);
         if (hipDeviceSynchronize() != hipSuccess) { h->err = "pack_posconv_w failed"; return bail(AMX_EHIP); }
     }
     // ---- encoder layers ----
@@ -455,20 +510,27 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
         ly.bqkv = (float*)dev_alloc(h, (size_t)3 * D * 4);
         if (!ly.wqkv || !ly.wo || !ly.w1 || !ly.w2 || !ly.bqkv) { h->err = "device allocation failed"; return bail(AMX_ENOMEM); }
         const char* names[3] = {"q_proj", "k_proj", "v_proj"};
+        const float ps_qkv = pack_scale({{tm.get(p + "attention.q_proj.weight"), qscale}, {tm.get(p + "attention.k_proj.weight"), 1.f},
+                                         {tm.get(p + "attention.v_proj.weight"), 1.f}});
+        ly.r_qkv = 1.f / ps_qkv;
         for (int j = 0; j < 3; ++j) {
             float sc = j == 0 ? qscale : 1.f;
-            TRY(pack_linear(h, tm, p + "attention." + names[j] + ".weight", D, D, sc, ly.wqkv, (int64_t)3 * D * D, D, j * D, D, staging));
+            TRY(pack_linear(h, tm, p + "attention." + names[j] + ".weight", D, D, sc * ps_qkv, ly.wqkv, (int64_t)3 * D * D, D, j * D, D, staging));
             const amx_tensor* b = tm.get(p + "attention." + names[j] + ".bias");
             if (!b || b->numel != D) { h->err = "missing tensor " + p + "attention." + names[j] + ".bias"; return bail(AMX_EINVAL); }
             if (hipMemcpy(staging, b->data, (size_t)D * 4, hipMemcpyHostToDevice) != hipSuccess) { h->err = "H2D failed"; return bail(AMX_EHIP); }
             launch_scale_copy(staging, ly.bqkv + j * D, D, sc, 0);
             if (hipDeviceSynchronize() != hipSuccess) { h->err = "scale_copy failed"; return bail(AMX_EHIP); }
         }
-        TRY(pack_linear(h, tm, p + "attention.out_proj.weight", D, D, 1.f, ly.wo, (int64_t)D * D, D, 0, D, staging));
+        const float ps_o = pack_scale({{tm.get(p + "attention.out_proj.weight"), 1.f}});
+        const float ps_1 = pack_scale({{tm.get(p + "feed_forward.intermediate_dense.weight"), 1.f}});
+        const float ps_2 = pack_scale({{tm.get(p + "feed_forward.output_dense.weight"), 1.f}});
+        ly.r_o = 1.f / ps_o; ly.r_1 = 1.f / ps_1; ly.r_2 = 1.f / ps_2;
+        TRY(pack_linear(h, tm, p + "attention.out_proj.weight", D, D, ps_o, ly.wo, (int64_t)D * D, D, 0, D, staging));
         TRY(upload_f32(h, tm, p + "attention.out_proj.bias", D, &ly.bo));
-        TRY(pack_linear(h, tm, p + "feed_forward.intermediate_dense.weight", F, D, 1.f, ly.w1, (int64_t)F * D, D, 0, D, staging));
+        TRY(pack_linear(h, tm, p + "feed_forward.intermediate_dense.weight", F, D, ps_1, ly.w1, (int64_t)F * D, D, 0, D, staging));
         TRY(upload_f32(h, tm, p + "feed_forward.intermediate_dense.bias", F, &ly.b1));
-        TRY(pack_linear(h, tm, p + "feed_forward.output_dense.weight", D, F, 1.f, ly.w2, (int64_t)D * F, F, 0, F, staging));
+        TRY(pack_linear(h, tm, p + "feed_forward.output_dense.weight", D, F, ps_2, ly.w2, (int64_t)D * F, F, 0, F, staging));
         TRY(upload_f32(h, tm, p + "feed_forward.output_dense.bias", D, &ly.b2));
     }
     TRY(upload_f32(h, tm, AM + "encoder.layer_norm.weight", D, &h->fln_g));
@@ -534,6 +596,17 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
         st.bias = (float*)dev_alloc(h, (size_t)st.rows * 4);
         if (!st.W || !st.bias) { h->err = "device allocation failed"; return bail(AMX_ENOMEM); }
         int row0 = 0;
+        float ps_w = 1.f;
+        {   // one scale for the stacked rows of the step
+            float m = 0.f;
+            for (int ci : st.classes) {
+                std::string key = PROJ + h->classes[ci].name + "._time_distributed_layer." + (st.time_heads > 0 ? "input_projection." : "") + "weight";
+                const amx_tensor* t = tm.get(key);
+                if (t) for (int64_t i = 0; i < t->numel; ++i) m = std::max(m, std::fabs(t->data[i]));
+            }
+            ps_w = pow2_for(m);
+        }
+        st.r_w = 1.f / ps_w;
         for (int ci : st.classes) {
             const amx_class_desc& c = h->classes[ci];
             std::string p = PROJ + c.name + "._time_distributed_layer.";
@@ -544,8 +617,11 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
                 st.tl_win = alloc_planes(h, plane_in);
                 st.tl_wout = alloc_planes(h, plane_out);
                 if (!st.tl_win || !st.tl_wout) { h->err = "device allocation failed"; return bail(AMX_ENOMEM); }
-                TRY(pack_linear(h, tm, p + "attention.in_proj_weight", 3 * Co, Co, 1.f, st.tl_win, plane_in, st.Cpad, 0, st.Cpad, staging));
-                TRY(pack_linear(h, tm, p + "attention.out_proj.weight", Co, Co, 1.f, st.tl_wout, plane_out, st.Cpad, 0, st.Cpad, staging));
+                const float ps_in = pack_scale({{tm.get(p + "attention.in_proj_weight"), 1.f}});
+                const float ps_out = pack_scale({{tm.get(p + "attention.out_proj.weight"), 1.f}});
+                st.r_tin = 1.f / ps_in; st.r_tout = 1.f / ps_out;
+                TRY(pack_linear(h, tm, p + "attention.in_proj_weight", 3 * Co, Co, ps_in, st.tl_win, plane_in, st.Cpad, 0, st.Cpad, staging));
+                TRY(pack_linear(h, tm, p + "attention.out_proj.weight", Co, Co, ps_out, st.tl_wout, plane_out, st.Cpad, 0, st.Cpad, staging));
                 TRY(upload_f32(h, tm, p + "attention.in_proj_bias", 3 * Co, &st.tl_bin));
                 TRY(upload_f32(h, tm, p + "attention.out_proj.bias", Co, &st.tl_bout));
                 TRY(upload_f32(h, tm, p + "layer_norm.weight", Co, &st.tl_g));
@@ -566,7 +642,7 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
                 }
                 p += "input_projection.";
             }
-            TRY(pack_linear(h, tm, p + "weight", c.out_features, st.K, 1.f, st.W, (int64_t)st.rows * st.Kpad, st.Kpad, row0, st.Kpad, staging));
+            TRY(pack_linear(h, tm, p + "weight", c.out_features, st.K, ps_w, st.W, (int64_t)st.rows * st.Kpad, st.Kpad, row0, st.Kpad, staging));
             const amx_tensor* b = tm.get(p + "bias");
             if (!b || b->numel != c.out_features) { h->err = "missing tensor " + p + "bias"; return bail(AMX_EINVAL); }
             if (hipMemcpy(st.bias + row0, b->data, (size_t)c.out_features * 4, hipMemcpyHostToDevice) != hipSuccess) { h->err = "H2D failed"; return bail(AMX_EHIP); }
@@ -582,9 +658,12 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
         const amx_tensor* t = tm.get(key);
         if (!t || t->numel % cfg->embedding_size) { h->err = "missing tensor " + key; return bail(AMX_EINVAL); }
         h->emb_rows = (int)(t->numel / cfg->embedding_size);
+        h->emb_host.assign(t->data, t->data + t->numel);
         TRY(upload_f32(h, tm, key, t->numel, &h->emb));
     }
 #undef TRY
+    h->nonfinite = (int*)dev_alloc(h, 16);
+    if (!h->nonfinite || hipMemset(h->nonfinite, 0, 16) != hipSuccess) { h->err = "device allocation failed"; return bail(AMX_ENOMEM); }
     if (h->composed_class < 0) {
         // no composition layer: one implicit inventory (fixed output widths)
         int rc2 = install_inventory(h, std::vector<int64_t>{}, std::vector<int64_t>{}, 0, 0, 0);
@@ -664,6 +743,7 @@ static void select_inventory(amx_handle h, int i) {
     e.last_use = ++h->inv_clock;
     h->inv = i;
     h->P1 = e.P1;
+    h->r_composed = e.r_composed;
     h->composed_w = e.composed_w;
     h->composed_f32 = e.composed_f32;
     h->out_unique_dev = e.out_unique_dev;
@@ -709,7 +789,21 @@ static int install_inventory(amx_handle h, std::vector<int64_t>&& key, const std
             return fail_free(AMX_ENOMEM, "inventory allocation failed");
         if (hipMemcpyAsync(e.idx_dev, idx.data(), idx.size() * 8, hipMemcpyHostToDevice, s) != hipSuccess)
             return fail_free(AMX_EHIP, "inventory upload failed");
-        launch_compose(h->prec, h->emb, E, e.idx_dev, P1, features, e.composed_f32, e.composed_w, (int64_t)P1 * E, E, s);
+        {   // largest entry of the composed matrix (sums of embedding rows), on the host
+            float m = 0.f;
+            for (int p = 0; p < P1; ++p)
+                for (int col = 0; col < E; ++col) {
+                    float acc = 0.f;
+                    for (int f = 0; f < features; ++f) {
+                        const int64_t r = idx[(size_t)p * features + f];
+                        if (r >= 0) acc += h->emb_host[(size_t)r * E + col];
+                    }
+                    m = std::max(m, std::fabs(acc));
+                }
+            const float ps = pow2_for(m);
+            e.r_composed = 1.f / ps;
+            launch_compose(h->prec, h->emb, E, e.idx_dev, P1, features, ps, e.composed_f32, e.composed_w, (int64_t)P1 * E, E, s);
+        }
         if (hipGetLastError() != hipSuccess) return fail_free(AMX_EHIP, "compose kernel launch failed");
     }
     // the uploads above read pageable host vectors that die with this call; a new inventory is a rare event (the cache
@@ -1072,6 +1166,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     HIPCHK(h, hipEventRecord(h->pin_event[slot], s));
     h->pin_busy[slot] = true;
 
+    HIPCHK(h, hipMemsetAsync(h->nonfinite, 0, 4, s));  // amx_check_finite reports on THIS forward pass
     // ---- input normalisation statistics + conv layer 0 (fused norm + conv + LN + GELU) ----
     { Timed t_(h, AMX_KC_OTHER); launch_audio_stats(d_audio, (const int64_t*)d_len, N, L, (double*)d_partial, (float*)d_stats, c.do_normalize, s); }
     { Timed t_(h, AMX_KC_CONV0); launch_conv0(prec, d_audio, (const int64_t*)d_len, (const float*)d_stats, N, L, (int)Ts[1], C, c.conv_kernel[0],
@@ -1088,7 +1183,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         g.a_batch_stride = Ts[i] * C;
         g.W = h->conv_w[i]; g.w_plane = (int64_t)C * C * c.conv_kernel[i]; g.ldw = (int64_t)C * c.conv_kernel[i];
         g.M = (int)rows_out; g.N = C; g.K = C * c.conv_kernel[i];
-        g.scale = 1.f; g.bias = h->conv_b[i];
+        g.scale = h->conv_r[i]; g.bias = h->conv_b[i];
         if (ragged) {  // honoured by the row-complete kernel only
             g.tile_list = d_tiles + tile_first[i];
             g.n_tiles = (int)(tile_first[i + 1] - tile_first[i]);
@@ -1133,7 +1228,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         g.A = cur; g.a_plane = cur_plane; g.lda = C; g.rows_per_batch = M; g.a_batch_stride = 0;
         g.W = h->fp_w; g.w_plane = (int64_t)D * C; g.ldw = C;
         g.M = (int)M; g.N = D; g.K = C;
-        g.scale = 1.f; g.bias = h->fp_bias;
+        g.scale = h->fp_r; g.bias = h->fp_bias;
         g.row_len = (const int*)d_frames; g.rows_T = T;
         g.out_f32 = (float*)hbuf; g.ldo = D;
         { Timed t_(h, gemm_class(prec, g)); run_gemm(prec, g, s); }
@@ -1147,7 +1242,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         if (!no_window && posconv_window_eligible(D, c.pos_groups, c.pos_kernel, N, T, Tpad, (int64_t)N * Tpad * D)) {
             Timed t_(h, AMX_KC_GEMM_TILE);
             launch_posconv_window(prec, hg, (int64_t)N * Tpad * D, h->pos_w, (int64_t)D * cg * c.pos_kernel,
-                                  (int64_t)cg * c.pos_kernel, h->pos_b, (float*)hbuf, N, T, Tpad, D, c.pos_groups, c.pos_kernel, s);
+                                  (int64_t)cg * c.pos_kernel, h->pos_b, h->pos_r, (float*)hbuf, N, T, Tpad, D, c.pos_groups, c.pos_kernel, s);
         } else {
         GemmParams g{};
         g.A = hg; g.a_plane = (int64_t)N * Tpad * D; g.lda = cg; g.rows_per_batch = T; g.a_batch_stride = (int64_t)Tpad * cg;
@@ -1155,7 +1250,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         g.W = h->pos_w; g.w_plane = (int64_t)D * cg * c.pos_kernel; g.ldw = (int64_t)cg * c.pos_kernel;
         g.zw = (int64_t)cg * cg * c.pos_kernel;
         g.M = (int)M; g.N = cg; g.K = cg * c.pos_kernel;
-        g.scale = 1.f; g.bias = h->pos_b; g.zbias = cg; g.act = 1;
+        g.scale = h->pos_r; g.bias = h->pos_b; g.zbias = cg; g.act = 1;
         g.residual = (const float*)hbuf; g.ldr = D; g.out_f32 = (float*)hbuf; g.ldo = D; g.zout = cg;
         { Timed t_(h, AMX_KC_GEMM_TILE); launch_gemm_grouped(prec, g, c.pos_groups, s); }
         }
@@ -1185,7 +1280,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             g.A = xp; g.a_plane = xp_plane; g.lda = D; g.rows_per_batch = Mrows;
             g.W = ly.wqkv; g.w_plane = (int64_t)3 * D * D; g.ldw = D;
             g.M = (int)Mrows; g.N = 3 * D; g.K = D;
-            g.scale = 1.f; g.bias = ly.bqkv;
+            g.scale = ly.r_qkv; g.bias = ly.bqkv;
             g.mode = 1; g.q = qb; g.k = kb; g.v = vtb;
             g.qk_plane = qk_plane;
             // packed rows: one "utterance" of Mp rows, so the scatter writes row m of head hh to [hh][m][:]
@@ -1208,7 +1303,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             g.A = ao; g.a_plane = xp_plane; g.lda = D; g.rows_per_batch = Mrows;
             g.W = ly.wo; g.w_plane = (int64_t)D * D; g.ldw = D;
             g.M = (int)Mrows; g.N = D; g.K = D;
-            g.scale = 1.f; g.bias = ly.bo;
+            g.scale = ly.r_o; g.bias = ly.bo;
             g.residual = (const float*)hbuf; g.ldr = D; g.out_f32 = (float*)hbuf; g.ldo = D;
             { Timed t_(h, gemm_class(prec, g)); run_gemm(prec, g, s); }
         }
@@ -1219,7 +1314,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             g.A = xp; g.a_plane = xp_plane; g.lda = D; g.rows_per_batch = Mrows;
             g.W = ly.w1; g.w_plane = (int64_t)F * D; g.ldw = D;
             g.M = (int)Mrows; g.N = F; g.K = D;
-            g.scale = 1.f; g.bias = ly.b1; g.act = 1;
+            g.scale = ly.r_1; g.bias = ly.b1; g.act = 1;
             g.out_p = ff; g.out_plane = Mrows * F; g.ldp = F;
             { Timed t_(h, gemm_class(prec, g)); run_gemm(prec, g, s); }
         }
@@ -1228,7 +1323,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             g.A = ff; g.a_plane = Mrows * F; g.lda = F; g.rows_per_batch = Mrows;
             g.W = ly.w2; g.w_plane = (int64_t)D * F; g.ldw = F;
             g.M = (int)Mrows; g.N = D; g.K = F;
-            g.scale = 1.f; g.bias = ly.b2;
+            g.scale = ly.r_2; g.bias = ly.b2;
             g.residual = (const float*)hbuf; g.ldr = D; g.out_f32 = (float*)hbuf; g.ldo = D;
             { Timed t_(h, gemm_class(prec, g)); run_gemm(prec, g, s); }
         }
@@ -1297,7 +1392,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         g.A = A; g.a_plane = a_plane; g.lda = lda; g.rows_per_batch = M;
         g.W = st.W; g.w_plane = (int64_t)st.rows * st.Kpad; g.ldw = st.Kpad;
         g.M = (int)M; g.N = st.rows; g.K = st.Kpad;
-        g.scale = 1.f; g.bias = st.bias;
+        g.scale = st.r_w; g.bias = st.bias;
         if (st.time_heads > 0) {
             // ProjectingMultiheadAttention.forward (acoustic_model.py:255-268)
             const int Co = st.rows, Cp = st.Cpad;
@@ -1309,7 +1404,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             gi.A = tl_p; gi.a_plane = M * Cp; gi.lda = Cp; gi.rows_per_batch = M;
             gi.W = st.tl_win; gi.w_plane = (int64_t)3 * Co * Cp; gi.ldw = Cp;
             gi.M = (int)M; gi.N = 3 * Co; gi.K = Cp;
-            gi.scale = 1.f; gi.bias = st.tl_bin;
+            gi.scale = st.r_tin; gi.bias = st.tl_bin;
             gi.out_f32 = (float*)tl_qkv; gi.ldo = 3 * Co;
             { Timed t_(h, gemm_class(prec, gi)); run_gemm(prec, gi, s); }
             { Timed t_(h, AMX_KC_OTHER); launch_time_attention(prec, (const float*)tl_qkv, (const int*)d_frames, N, T, Co, st.time_heads,
@@ -1319,7 +1414,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             g.A = tl_p; g.a_plane = M * Cp; g.lda = Cp; g.rows_per_batch = M;
             g.W = st.tl_wout; g.w_plane = (int64_t)Co * Cp; g.ldw = Cp;
             g.M = (int)M; g.N = Co; g.K = Cp;
-            g.scale = 1.f; g.bias = st.tl_bout;
+            g.scale = st.r_tout; g.bias = st.tl_bout;
         }
         if (st.composed) {
             g.out_p = ebuf; g.out_plane = M * E; g.ldp = E;
@@ -1329,7 +1424,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             g2.A = ebuf; g2.a_plane = M * E; g2.lda = E; g2.rows_per_batch = M;
             g2.W = h->composed_w; g2.w_plane = (int64_t)h->P1 * E; g2.ldw = E;
             g2.M = (int)M; g2.N = h->P1; g2.K = E;
-            g2.scale = 1.0f / sqrtf((float)E);
+            g2.scale = h->r_composed / sqrtf((float)E);
             g2.out_f32 = (float*)logits + h->col[st.classes[0]]; g2.ldo = h->ld_logits;
             { Timed t_(h, gemm_class(prec, g2)); run_gemm(prec, g2, s); }
         } else {
@@ -1338,7 +1433,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         }
     }
     { Timed t_(h, AMX_KC_OTHER); launch_logsoftmax_out(h->out_unique_dev, (int)h->out_unique.size(), (const float*)logits, h->ld_logits, N, T,
-                          (const int*)d_frames, (flags & AMX_FLAG_RAW_LOGITS) ? 0 : 1, d_out, s); }
+                          (const int*)d_frames, (flags & AMX_FLAG_RAW_LOGITS) ? 0 : 1, d_out, h->nonfinite, s); }
     HIPCHK(h, hipGetLastError());
     if (flags & AMX_FLAG_HOST_IO) {
         HIPCHK(h, hipMemcpyAsync(out, d_out, (size_t)total * 4, hipMemcpyDeviceToHost, s));
@@ -1355,6 +1450,20 @@ extern "C" int amx_synchronize(amx_handle h, void* stream) {
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
     HIPCHK(h, hipGetLastError());
+    return AMX_OK;
+}
+
+extern "C" int amx_check_finite(amx_handle h, void* stream, int64_t* frames) {
+    if (!h) return AMX_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+    int count = 0;
+    HIPCHK(h, hipMemcpy(&count, h->nonfinite, 4, hipMemcpyDeviceToHost));
+    if (frames) *frames = count;
+    if (count > 0)
+        return fail(h, AMX_ERANGE, std::to_string(count) + " valid frame(s) of the last forward pass hold non-finite logits: an activation left the "
+                                   "range of the 16-bit planes (fp16: |x| <= 65504) or the input was not finite; the bf16 planes "
+                                   "(precision bf16x3) have the range of fp32");
     return AMX_OK;
 }
 

@@ -267,7 +267,7 @@ void launch_posconv_pack(int prec, const float* h, int N, int T, int D, int G, i
 // image [G][N][Tpad][64] and the weights [G][64][taps * 64]; eligible when hidden / groups == 64 and taps <= 128
 bool posconv_window_eligible(int D, int G, int taps, int N, int Tn, int Tpad, int64_t image_plane);
 void launch_posconv_window(int prec, const void* image, int64_t image_plane, const void* weights, int64_t w_plane, int64_t ldw,
-                           const float* bias, float* h, int N, int Tn, int Tpad, int D, int G, int taps, hipStream_t s);
+                           const float* bias, float scale, float* h, int N, int Tn, int Tpad, int D, int G, int taps, hipStream_t s);
 
 struct ConcatPart {
     int type;     // 0: fp32 hidden rows -> planes; 1: softmax over logits columns
@@ -293,8 +293,9 @@ struct OutDesc {
     int64_t prefix;   // classes of all earlier output blocks: the [T,N,C] block starts at T * N * prefix floats
                       // (geometry-independent, so the device table only changes with the inventory)
 };
+// `nonfinite` (device counter, may be null): incremented once per valid frame whose logits hold a NaN or an infinity
 void launch_logsoftmax_out(const OutDesc* descs_dev, int n_out, const float* logits, int64_t ld, int N, int T,
-                           const int* frame_len, int log_probs, float* out, hipStream_t s);
+                           const int* frame_len, int log_probs, float* out, int* nonfinite, hipStream_t s);
 void launch_greedy_ctc(const OutDesc* descs_dev, int n_out, const float* out, const int* frame_len, int N, int T,
                        int64_t* tokens, int64_t* timesteps, int* counts, float* scores, hipStream_t s);
 // the same decoder over one [N, T, C] emission tensor with element strides (stride_n, stride_t, 1)
@@ -304,12 +305,15 @@ void launch_greedy_ctc_emissions(const float* emissions, int64_t stride_n, int64
 // weight packing helpers (device side; run once at amx_create / amx_set_inventory)
 void launch_pack_matrix(int prec, const float* src, int rows, int cols, int64_t src_row_stride, int64_t src_col_stride,
                         float scale, void* dst, int64_t dst_plane, int64_t ldd, int cols_pad, hipStream_t s);
-void launch_pack_conv_w(int prec, const float* src /*[Co,Ci,k]*/, int Co, int Ci, int k, void* dst, int64_t dst_plane,
+// (`scale`: the weights are multiplied by it before the 16-bit split -- a per-tensor power of two chosen at amx_create so
+// that the largest weight lands in [4096, 8192): the lo plane of an fp16 pair is only a normal number, i.e. only carries its
+// full 11 bits, for |w| >= 0.25, and the hi plane underflows below 6e-5; the product's epilogue multiplies by 1 / scale)
+void launch_pack_conv_w(int prec, const float* src /*[Co,Ci,k]*/, int Co, int Ci, int k, float scale, void* dst, int64_t dst_plane,
                         hipStream_t s);
-void launch_pack_posconv_w(int prec, const float* g /*[k]*/, const float* v /*[D,cg,k]*/, int D, int cg, int k,
+void launch_pack_posconv_w(int prec, const float* g /*[k]*/, const float* v /*[D,cg,k]*/, int D, int cg, int k, float scale,
                            float* norm_scratch, void* dst /*[G][cg][k*cg]*/, int64_t dst_plane, hipStream_t s);
 void launch_compose(int prec, const float* emb, int E, const int64_t* idx /*[P+1, F] absolute rows, row 0 = blank*/,
-                    int P1, int F, float* composed_f32 /*[P1,E]*/, void* dst, int64_t dst_plane, int64_t ldd,
+                    int P1, int F, float scale, float* composed_f32 /*[P1,E]*/, void* dst, int64_t dst_plane, int64_t ldd,
                     hipStream_t s);
 void launch_scale_copy(const float* src, float* dst, int64_t n, float scale, hipStream_t s);
 

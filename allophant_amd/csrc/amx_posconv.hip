@@ -34,7 +34,7 @@ template <typename T, int NT>
 __global__ __launch_bounds__(512, 2) void posconv_window_kernel(const T* __restrict__ image, int64_t image_plane,
                                                                 const T* __restrict__ weights, int64_t w_plane, int64_t ldw,
                                                                 const float* __restrict__ bias, float* __restrict__ h,
-                                                                int N, int Tn, int Tpad, int D, int taps) {
+                                                                int N, int Tn, int Tpad, int D, int taps, float scale) {
     typedef typename Vec8<T>::type V8;
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(512, 2) void posconv_window_kernel(const T* __restr
         multiply_tap(j + 1);
     }
 
-    // ---- epilogue: h += gelu(acc + bias); acc[ni][mi][r] is frame 16 mi + (lane & 15), channel 16 ni + 4 (lane >> 4) + r ----
+    // ---- epilogue: h += gelu(acc * scale + bias) (scale: the power of two the packed weights were divided by); acc[ni][mi][r] is frame 16 mi + (lane & 15), channel 16 ni + 4 (lane >> 4) + r ----
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
         const int t = t0 + wave * 32 + mi * 16 + (lane & 15);
@@ -151,8 +151,8 @@ __global__ __launch_bounds__(512, 2) void posconv_window_kernel(const T* __restr
             const int c = ni * 16 + 4 * (lane >> 4);
             const float4 b4 = *(const float4*)(bias + g * PC_CG + c);
             float4 r4 = *(const float4*)(row + c);
-            const f32x2 g01 = gelu_fast2(f32x2{acc[ni][mi][0] + b4.x, acc[ni][mi][1] + b4.y});
-            const f32x2 g23 = gelu_fast2(f32x2{acc[ni][mi][2] + b4.z, acc[ni][mi][3] + b4.w});
+            const f32x2 g01 = gelu_fast2(f32x2{fmaf(acc[ni][mi][0], scale, b4.x), fmaf(acc[ni][mi][1], scale, b4.y)});
+            const f32x2 g23 = gelu_fast2(f32x2{fmaf(acc[ni][mi][2], scale, b4.z), fmaf(acc[ni][mi][3], scale, b4.w)});
             r4.x += g01[0];
             r4.y += g01[1];
             r4.z += g23[0];
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(512, 2) void posconv_window_kernel(const T* __restr
 
 template <typename T, int NT>
 void launch_posconv_t(const void* image, int64_t image_plane, const void* weights, int64_t w_plane, int64_t ldw,
-                      const float* bias, float* h, int N, int Tn, int Tpad, int D, int G, int taps, hipStream_t s) {
+                      const float* bias, float scale, float* h, int N, int Tn, int Tpad, int D, int G, int taps, hipStream_t s) {
     constexpr int lds = NT * PC_WIN * 128 + PC_STAGES * NT * PC_WTAP;
     static OncePerDevice attr;
     if (attr.first())
@@ -173,7 +173,7 @@ void launch_posconv_t(const void* image, int64_t image_plane, const void* weight
     const int tiles_per_utt = (Tn + PC_ROWS - 1) / PC_ROWS;
     dim3 grid((unsigned)(N * tiles_per_utt), (unsigned)G);
     hipLaunchKernelGGL((posconv_window_kernel<T, NT>), grid, dim3(512), lds, s, (const T*)image, image_plane, (const T*)weights,
-                       w_plane, ldw, bias, h, N, Tn, Tpad, D, taps);
+                       w_plane, ldw, bias, h, N, Tn, Tpad, D, taps, scale);
 }
 
 }  // namespace
@@ -198,12 +198,12 @@ bool posconv_window_eligible(int D, int G, int taps, int N, int Tn, int Tpad, in
 }
 
 void launch_posconv_window(int prec, const void* image, int64_t image_plane, const void* weights, int64_t w_plane, int64_t ldw,
-                           const float* bias, float* h, int N, int Tn, int Tpad, int D, int G, int taps, hipStream_t s) {
+                           const float* bias, float scale, float* h, int N, int Tn, int Tpad, int D, int G, int taps, hipStream_t s) {
     switch (prec) {
-        case PREC_BF16: launch_posconv_t<bf16, 1>(image, image_plane, weights, w_plane, ldw, bias, h, N, Tn, Tpad, D, G, taps, s); break;
-        case PREC_F16: launch_posconv_t<f16, 1>(image, image_plane, weights, w_plane, ldw, bias, h, N, Tn, Tpad, D, G, taps, s); break;
-        case PREC_BF16X3: launch_posconv_t<bf16, 2>(image, image_plane, weights, w_plane, ldw, bias, h, N, Tn, Tpad, D, G, taps, s); break;
-        default: launch_posconv_t<f16, 2>(image, image_plane, weights, w_plane, ldw, bias, h, N, Tn, Tpad, D, G, taps, s); break;
+        case PREC_BF16: launch_posconv_t<bf16, 1>(image, image_plane, weights, w_plane, ldw, bias, scale, h, N, Tn, Tpad, D, G, taps, s); break;
+        case PREC_F16: launch_posconv_t<f16, 1>(image, image_plane, weights, w_plane, ldw, bias, scale, h, N, Tn, Tpad, D, G, taps, s); break;
+        case PREC_BF16X3: launch_posconv_t<bf16, 2>(image, image_plane, weights, w_plane, ldw, bias, scale, h, N, Tn, Tpad, D, G, taps, s); break;
+        default: launch_posconv_t<f16, 2>(image, image_plane, weights, w_plane, ldw, bias, scale, h, N, Tn, Tpad, D, G, taps, s); break;
     }
 }
 

@@ -551,7 +551,7 @@ __global__ __launch_bounds__(256) void time_attention_kernel(const float* __rest
 __global__ __launch_bounds__(256) void logsoftmax_out_kernel(const OutDesc* __restrict__ descs, int n_out,
                                                              const float* __restrict__ logits, int64_t ld, int N, int T,
                                                              const int* __restrict__ frame_len, int log_probs,
-                                                             float* __restrict__ out) {
+                                                             float* __restrict__ out, int* __restrict__ nonfinite) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // row = n*T + t
     if (row >= (int64_t)N * T) return;
@@ -565,6 +565,16 @@ __global__ __launch_bounds__(256) void logsoftmax_out_kernel(const OutDesc* __re
         return;
     }
     const float* src_row = logits + row * ld;
+    if (nonfinite) {
+        // range check of the 16-bit planes (fp16 overflows at 65504): whatever overflowed upstream has become an infinity or
+        // a NaN in this frame's logits by now (amx_check_finite reads the counter)
+        bool bad = false;
+        for (int o = 0; o < n_out; ++o) {
+            const OutDesc d = descs[o];
+            for (int c = lane; c < d.C; c += 64) bad |= !__builtin_isfinite(src_row[d.col + c]);
+        }
+        if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicAdd(nonfinite, 1);
+    }
     // narrow outputs (the attribute classifiers: 4 classes each): one LANE per output, everything lane-local -- a wave
     // reduction per 4-class output (36 of them per frame) made this kernel 20x slower than its 11 MB of traffic
     constexpr int NARROW = 8;
@@ -714,7 +724,7 @@ __global__ void pack_matrix_kernel(const float* __restrict__ src, int rows, int 
 }
 
 template <typename T, int NT>
-__global__ void pack_conv_w_kernel(const float* __restrict__ src, int Co, int Ci, int k, T* __restrict__ dst,
+__global__ void pack_conv_w_kernel(const float* __restrict__ src, int Co, int Ci, int k, float scale, T* __restrict__ dst,
                                    int64_t dst_plane) {
     // dst[co][j*Ci + ci] = src[co][ci][j]
     int64_t total = (int64_t)Co * Ci * k;
@@ -724,7 +734,7 @@ __global__ void pack_conv_w_kernel(const float* __restrict__ src, int Co, int Ci
         int j = (int)(r % k);
         int co = (int)(r / k);
         T hi, lo;
-        split16<T, NT>(src[((int64_t)co * Ci + ci) * k + j], hi, lo);
+        split16<T, NT>(src[((int64_t)co * Ci + ci) * k + j] * scale, hi, lo);
         dst[i] = hi;
         if (NT > 1) dst[dst_plane + i] = lo;
     }
@@ -749,7 +759,7 @@ __global__ __launch_bounds__(256) void posconv_norm_kernel(const float* __restri
 
 template <typename T, int NT>
 __global__ void pack_posconv_w_kernel(const float* __restrict__ g, const float* __restrict__ v, const float* __restrict__ norm,
-                                      int D, int cg, int k, T* __restrict__ dst, int64_t dst_plane) {
+                                      int D, int cg, int k, float scale, T* __restrict__ dst, int64_t dst_plane) {
     // dst[grp][co][tap*cg + ci] = v[grp*cg + co][ci][tap] * (g[tap] / norm[tap])
     int64_t total = (int64_t)D * cg * k;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -757,7 +767,7 @@ __global__ void pack_posconv_w_kernel(const float* __restrict__ g, const float* 
         int64_t r = i / cg;
         int tap = (int)(r % k);
         int co_all = (int)(r / k);  // grp*cg + co
-        float w = v[((int64_t)co_all * cg + ci) * k + tap] * (g[tap] / norm[tap]);
+        float w = v[((int64_t)co_all * cg + ci) * k + tap] * (g[tap] / norm[tap]) * scale;
         T hi, lo;
         split16<T, NT>(w, hi, lo);
         dst[i] = hi;
@@ -766,7 +776,7 @@ __global__ void pack_posconv_w_kernel(const float* __restrict__ g, const float* 
 }
 
 template <typename T, int NT>
-__global__ void compose_kernel(const float* __restrict__ emb, int E, const int64_t* __restrict__ idx, int P1, int F,
+__global__ void compose_kernel(const float* __restrict__ emb, int E, const int64_t* __restrict__ idx, int P1, int F, float scale,
                                float* __restrict__ composed, T* __restrict__ dst, int64_t dst_plane, int64_t ldd) {
     // EmbeddingBag(mode="sum") per phone (reference acoustic_model.py:219-232); negative index = unused slot
     int64_t total = (int64_t)P1 * E;
@@ -779,7 +789,7 @@ __global__ void compose_kernel(const float* __restrict__ emb, int E, const int64
         }
         composed[i] = s;
         T hi, lo;
-        split16<T, NT>(s, hi, lo);
+        split16<T, NT>(s * scale, hi, lo);
         dst[(int64_t)p * ldd + e] = hi;
         if (NT > 1) dst[dst_plane + (int64_t)p * ldd + e] = lo;
     }
@@ -893,10 +903,10 @@ void launch_time_attention(int prec, const float* qkv, const int* frame_len, int
 }
 
 void launch_logsoftmax_out(const OutDesc* descs_dev, int n_out, const float* logits, int64_t ld, int N, int T,
-                           const int* frame_len, int log_probs, float* out, hipStream_t s) {
+                           const int* frame_len, int log_probs, float* out, int* nonfinite, hipStream_t s) {
     int64_t M = (int64_t)N * T;
     hipLaunchKernelGGL(logsoftmax_out_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, descs_dev, n_out, logits, ld,
-                       N, T, frame_len, log_probs, out);
+                       N, T, frame_len, log_probs, out, nonfinite);
 }
 
 void launch_greedy_ctc(const OutDesc* descs_dev, int n_out, const float* out, const int* frame_len, int N, int T,
@@ -920,25 +930,25 @@ void launch_pack_matrix(int prec, const float* src, int rows, int cols, int64_t 
                                           cols, src_row_stride, src_col_stride, scale, (T16*)dst, dst_plane, ldd, cols_pad));
 }
 
-void launch_pack_conv_w(int prec, const float* src, int Co, int Ci, int k, void* dst, int64_t dst_plane, hipStream_t s) {
+void launch_pack_conv_w(int prec, const float* src, int Co, int Ci, int k, float scale, void* dst, int64_t dst_plane, hipStream_t s) {
     int64_t total = (int64_t)Co * Ci * k;
     AMX_DISPATCH(prec, hipLaunchKernelGGL((pack_conv_w_kernel<T16, NT>), dim3(grid_for(total)), dim3(256), 0, s, src, Co, Ci, k,
-                                          (T16*)dst, dst_plane));
+                                          scale, (T16*)dst, dst_plane));
 }
 
-void launch_pack_posconv_w(int prec, const float* g, const float* v, int D, int cg, int k, float* norm_scratch, void* dst,
+void launch_pack_posconv_w(int prec, const float* g, const float* v, int D, int cg, int k, float scale, float* norm_scratch, void* dst,
                            int64_t dst_plane, hipStream_t s) {
     hipLaunchKernelGGL(posconv_norm_kernel, dim3(k), dim3(256), 0, s, v, (int64_t)D * cg, k, norm_scratch);
     int64_t total = (int64_t)D * cg * k;
     AMX_DISPATCH(prec, hipLaunchKernelGGL((pack_posconv_w_kernel<T16, NT>), dim3(grid_for(total)), dim3(256), 0, s, g, v,
-                                          norm_scratch, D, cg, k, (T16*)dst, dst_plane));
+                                          norm_scratch, D, cg, k, scale, (T16*)dst, dst_plane));
 }
 
-void launch_compose(int prec, const float* emb, int E, const int64_t* idx, int P1, int F, float* composed_f32, void* dst,
+void launch_compose(int prec, const float* emb, int E, const int64_t* idx, int P1, int F, float scale, float* composed_f32, void* dst,
                     int64_t dst_plane, int64_t ldd, hipStream_t s) {
     int64_t total = (int64_t)P1 * E;
     AMX_DISPATCH(prec, hipLaunchKernelGGL((compose_kernel<T16, NT>), dim3(grid_for(total)), dim3(256), 0, s, emb, E, idx, P1, F,
-                                          composed_f32, (T16*)dst, dst_plane, ldd));
+                                          scale, composed_f32, (T16*)dst, dst_plane, ldd));
 }
 
 void launch_scale_copy(const float* src, float* dst, int64_t n, float scale, hipStream_t s) {

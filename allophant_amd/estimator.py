@@ -429,6 +429,14 @@ class Estimator:
         _lib.check(self._lib, self._handle, self._lib.amx_timing_fetch(self._handle, ms, launches, n))
         return {k: (float(ms[i]), int(launches[i])) for i, k in enumerate(_lib.KERNEL_CLASSES)}
 
+    def check_finite(self) -> None:
+        """Range check of the last ``predict`` (``amx_check_finite``; no upstream counterpart -- the reference computes in
+        fp32): waits for the stream and raises ``FloatingPointError`` when a valid frame holds non-finite logits, i.e. an
+        activation left the range of the fp16 planes (|x| <= 65504) or the audio was not finite.  Weights cannot cause it:
+        they are packed under per-tensor power-of-two scales.  ``precision="bf16x3"`` has the range of fp32."""
+        stream = torch.cuda.current_stream(self._device).cuda_stream
+        _lib.check(self._lib, self._handle, self._lib.amx_check_finite(self._handle, C.c_void_p(stream), None))
+
     def synchronize(self) -> None:
         stream = torch.cuda.current_stream(self._device).cuda_stream
         _lib.check(self._lib, self._handle, self._lib.amx_synchronize(self._handle, C.c_void_p(stream)))

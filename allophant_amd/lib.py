@@ -14,7 +14,7 @@ AMX_MAX_CONV = 8
 AMX_MAX_DEPS = 64
 AMX_NAME_LEN = 48
 
-AMX_OK, AMX_EINVAL, AMX_EHIP, AMX_ESTATE, AMX_ENOMEM = 0, -1, -2, -3, -4
+AMX_OK, AMX_EINVAL, AMX_EHIP, AMX_ESTATE, AMX_ENOMEM, AMX_ERANGE = 0, -1, -2, -3, -4, -5
 PRECISIONS = {"bf16": 0, "f16": 1, "bf16x3": 2, "f16x3": 3}
 FLAG_HOST_IO, FLAG_RAW_LOGITS, FLAG_KEEP_HIDDEN, FLAG_TIMING, FLAG_PADDED, FLAG_NO_PACK = 1, 2, 4, 8, 16, 32
 KERNEL_CLASSES = ["gemm_pp", "gemm_tile", "attention", "rownorm", "conv0", "other", "gemm_ln", "conv_tail"]
@@ -28,7 +28,7 @@ LIB_PATH = os.environ.get("AMX_LIB_PATH") or os.path.join(os.path.dirname(os.pat
 EXPORTS = [
     "amx_create", "amx_destroy", "amx_last_error", "amx_set_inventory", "amx_output_layout", "amx_forward",
     "amx_synchronize", "amx_greedy_ctc", "amx_debug_fetch", "amx_device_bytes", "amx_timing_fetch",
-    "amx_max_utterances", "amx_greedy_ctc_emissions",
+    "amx_max_utterances", "amx_greedy_ctc_emissions", "amx_check_finite",
 ]
 
 
@@ -93,6 +93,8 @@ def load() -> C.CDLL:
     lib.amx_forward.restype = i32
     lib.amx_synchronize.argtypes = [vp, vp]
     lib.amx_synchronize.restype = i32
+    lib.amx_check_finite.argtypes = [vp, vp, C.POINTER(i64)]
+    lib.amx_check_finite.restype = i32
     lib.amx_greedy_ctc.argtypes = [vp, vp, C.POINTER(i64), i32, i64, vp, vp, vp, vp, vp]
     lib.amx_greedy_ctc.restype = i32
     lib.amx_debug_fetch.argtypes = [vp, i32, i32, vp, i64, C.POINTER(i64)]
@@ -120,4 +122,6 @@ def check(lib: C.CDLL, handle, code: int) -> None:
         raise ValueError(message)
     if code == AMX_ENOMEM:
         raise MemoryError(message)
+    if code == AMX_ERANGE:
+        raise FloatingPointError(message)
     raise RuntimeError(message)

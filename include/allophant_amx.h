@@ -34,6 +34,7 @@ extern "C" {
 #define AMX_EHIP (-2)     /* HIP runtime failure */
 #define AMX_ESTATE (-3)   /* call order violated (e.g. composition model without an inventory) */
 #define AMX_ENOMEM (-4)
+#define AMX_ERANGE (-5)   /* amx_check_finite: an activation left the range of the 16-bit planes (non-finite logits) */
 
 /* arithmetic modes of the GEMM-shaped products (activations between kernels are 16-bit planes, residual stream,
  * LayerNorm, softmax and all accumulation are fp32):
@@ -164,6 +165,13 @@ int64_t amx_max_utterances(amx_handle h, int64_t L);
 int amx_forward(amx_handle h, const float* audio, const int64_t* lengths, int N, int64_t L, float* out,
                 int64_t* out_lengths, uint32_t flags, void* stream);
 int amx_synchronize(amx_handle h, void* stream);
+
+/* Range check of the last amx_forward on `stream` (no upstream counterpart: the reference computes in fp32).  The 16-bit
+ * planes of the fp16 modes hold |x| <= 65504; weights are packed under a per-tensor power-of-two scale, so only an
+ * ACTIVATION (or a non-finite input sample) can leave that range, and it then reaches the logits as an infinity or a NaN.
+ * Waits for `stream`, stores the number of valid frames with non-finite logits in *frames (may be NULL) and returns AMX_OK
+ * when there are none, AMX_ERANGE otherwise (amx_last_error names the remedy: precision bf16x3 has the range of fp32). */
+int amx_check_finite(amx_handle h, void* stream, int64_t* frames);
 
 /* Replaces `GreedyCTCDecoder.__call__` (predictions.py:194-207), applied to every output of a prediction as the
  * reference's decode loop does (run.py:767-774): `out` is the device output buffer amx_forward filled for a batch of
