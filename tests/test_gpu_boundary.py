@@ -71,6 +71,49 @@ def test_restored_composition_checkpoint_predicts_with_the_training_inventory(am
     est.close()
 
 
+def test_restore_takes_the_branch_of_a_real_checkpoint(amd, tmp_path):
+    """The branch a real ``allophant.pt`` takes through ``Estimator.restore`` (reference estimator.py:229-249, 1085-1126): no
+    private ``amx_*`` key anywhere -- the XLS-R-300m shape comes from ``nn.acoustic_model.model_id``, the embedding-table
+    layout from the embedded attribute table, ``shared_phones`` from the shape of ``_allophone_matrices`` -- through a
+    ``torch.save``d file, at full XLS-R shape, predicting with the restored training inventory against the oracle."""
+    from oracle import allophant_oracle as O
+    from allophant_amd.checkpoint import make_checkpoint
+
+    with open(os.path.join(GOLDEN_DIR, "g9_restricted_indexer.json"), encoding="utf-8") as f:
+        g9 = json.load(f)
+    shared = g9["state"]["language_allophones"]["shared_phones"]
+    phonemes = g9["state"]["phoneme_inventory"]
+    spec = S.multitask_spec(S.xlsr_300m_encoder(), ["syllabic", "long", "nasal"], embedding_size=640, train_phonemes=len(phonemes),
+                            n_features=len(g9["training_matrix"][0]), allophone_layer=True)
+    spec["shared_phones"] = len(shared)
+    offsets = g9["category_offsets"]
+    spec["composition_categories"] = [b - a for a, b in zip(offsets, offsets[1:] + [g9["embedding_rows"]])]
+    state = synthetic.make_state_dict(spec, seed=7)
+    matrices = state["_projection._layers.phoneme._allophone_layer._allophone_matrices"]
+    assert matrices.shape[1] == len(shared) + 1 and matrices.shape[2] == len(phonemes) + 1
+    checkpoint = make_checkpoint(spec, state, synthetic_encoder=False, indexer_state=g9["state"])
+    checkpoint["additional"] = {}  # what upstream stores there is user data; nothing of ours
+    assert "amx" not in json.dumps({k: v for k, v in checkpoint.items() if k != "model_state"})
+    assert checkpoint["config"]["nn"]["acoustic_model"]["model_id"] == "facebook/wav2vec2-xls-r-300m"
+    path = tmp_path / "allophant.pt"
+    torch.save(checkpoint, path)
+    est, indexer = amd.Estimator.restore(str(path), "cuda:0")
+    assert est._spec["hidden"] == 1024 and est._spec["layers"] == 24 and est._spec["shared_phones"] == len(shared)
+    assert est._spec["composition_categories"] == spec["composition_categories"]
+    training = torch.tensor(g9["training_matrix"], dtype=torch.int64)
+    assert torch.equal(est._training_inventory, training)
+    audio, lengths = synthetic.make_audio(2, 32000, seed=12, ragged=True)
+    pred = est.predict(amd.Batch(audio.cuda(), lengths, torch.zeros(2, dtype=torch.long)))  # training inventory
+    ref, ref_len = O.predict(audio, lengths, state, spec, training, synthetic.category_offsets(spec))
+    assert list(pred.outputs) == list(ref) == ["syllabic", "long", "nasal", "phone", "phoneme"]
+    assert torch.equal(pred.lengths.cpu(), ref_len)
+    assert max(max_abs_valid_tm(pred.outputs[k].cpu(), ref[k], ref_len) for k in ref) < GATE
+    es = indexer.composition_feature_matrix(indexer.phoneme_inventory("spa"))
+    assert est.predict(amd.Batch(audio.cuda(), lengths, torch.zeros(2, dtype=torch.long)), es).outputs["phoneme"].shape[-1] == \
+        len(g9["inventories"]["spa"]) + 1
+    est.close()
+
+
 def test_estimator_without_training_inventory_still_raises(amd):
     spec = S.multitask_spec(S.tiny_encoder(1), ["syllabic"], embedding_size=16, train_phonemes=5, n_features=3)
     est = amd.Estimator(spec, synthetic.make_state_dict(spec, seed=1), "cuda:0")
