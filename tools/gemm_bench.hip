@@ -233,6 +233,10 @@ int main(int argc, char** argv) {
 #ifdef AMX_PP_STAMP
     if (argc > 1 && !strcmp(argv[1], "stamp")) {
         int precs[] = {PREC_F16X3, PREC_BF16, PREC_F16};
+        if (argc > 4) {  // stamp <M> <N> <K>: one shape, f16x3
+            run_stamp(PREC_F16X3, atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), "custom");
+            return 0;
+        }
         for (int prec : precs) {
             run_stamp(prec, 15968, 4096, 1024, "ffn1-like");
             run_stamp(prec, 15968, 1024, 4096, "ffn2-like");
@@ -255,13 +259,13 @@ int main(int argc, char** argv) {
         g.A = A; g.a_plane = a_el; g.lda = K; g.rows_per_batch = M; g.W = W; g.w_plane = w_el; g.ldw = K; g.M = M; g.N = N; g.K = K;
         g.scale = 1.f; g.bias = bias; g.act = 1; g.out_p = outp; g.out_plane = o_el; g.ldp = N;
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-        double total_ms = 0; long launches = 0;
+        double total_ms = 0;
         while (total_ms < seconds * 1e3) {
             CK(hipEventRecord(e0, 0));
             for (int i = 0; i < 200; ++i) launch_gemm(prec, g, 0);
             CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-            total_ms += ms; launches += 200;
+            total_ms += ms;
             printf("SOAK %.1f us per launch (200 launches)\n", ms * 1e3 / 200); fflush(stdout);
         }
         return 0;
