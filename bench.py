@@ -45,7 +45,7 @@ from allophant_amd import spec as S, synthetic  # noqa: E402
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/f16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 HBM_PEAK_GBS = 8000.0
 MEASURED_MFMA_CEILING_TFLOPS = 2100.0  # 16x16x32 f16, two waves per SIMD (profiles/r02_mfma_only_ceiling.log)
-MEASURED_STORE_CEILING_GBS = 5100.0  # best pure-store rate of tools/hbm_bw_probe.hip on an MI355X (profiles/r02_hbm_bw.log)
+CONV0_PATTERN_STORE_GBS = 5660.0  # conv0's own store pattern without its arithmetic (tools/store_bw_probe.hip, profiles/r03_store_bw.log)
 TRAFFIC_FILES = ("r03_traffic.json", "r02_traffic.json")  # newest first; written by tools/collect_profiles.py
 
 
@@ -407,11 +407,12 @@ def main():
                     "bound": "hbm", "algorithmic_bytes": w["conv0_bytes"], "ms": conv0_ms, "achieved": conv0_gbs,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": conv0_gbs / HBM_PEAK_GBS if conv0_gbs else None,
                     "traffic": traffic.get("conv0_hbm_bytes_per_launch"),
-                    # 99 % of this kernel's bytes are stores.  For scale only: what this repo's own pure-store probe reaches
-                    # (tools/hbm_bw_probe.hip; the microarch guide records 6.0-6.2 TB/s for plain stores) -- `frac` above, against
-                    # the 8 TB/s peak, is the roofline figure
-                    "own_store_probe_gbs": MEASURED_STORE_CEILING_GBS,
-                    "frac_of_own_probe": conv0_gbs / MEASURED_STORE_CEILING_GBS if conv0_gbs else None,
+                    # 99 % of this kernel's bytes are stores.  For scale only: the rate of its own store pattern with the
+                    # arithmetic removed (tools/store_bw_probe.hip: 5.64-5.68 TB/s; pure store streams reach 5.3-6.6 TB/s by
+                    # shape) -- the kernel is VALU-bound (0.45 ms without its stores); `frac` above,
+                    # against the 8 TB/s peak, is the roofline figure
+                    "own_store_probe_gbs": CONV0_PATTERN_STORE_GBS,
+                    "frac_of_own_probe": conv0_gbs / CONV0_PATTERN_STORE_GBS if conv0_gbs else None,
                 },
                 "conv1_5": {
                     "kernel": "gemm_ln_kernel<T16, planes>: 128x512 row-complete implicit GEMM + LayerNorm + GELU",
@@ -621,6 +622,8 @@ def main():
                 }
             except Exception as exc:
                 result["parity_spot_check"] = {"error": repr(exc)}
+    if use_dist:
+        dist.barrier()  # the other ranks stay until rank 0 has finished its spot check: every rank leaves the group together
     sys.stdout.flush()
     os.dup2(saved_stdout, 1)
     os.close(saved_stdout)

@@ -184,3 +184,33 @@ def test_mask_and_length_helpers_match_reference_goldens():
     assert torch.equal(utils.mask_sequence(lengths, batch_first=False), mask.t())
     assert utils.mask_sequence(lengths, max_length=4).shape == (3, 4)
     assert utils.mask_sequence(lengths, max_length=9, start=2).shape == (3, 7)
+
+
+def test_bench_helpers_hash_gate_and_core_count(tmp_path, monkeypatch):
+    """bench.py hygiene (round-2 review, item 8): `roofline.traffic` is only reported from a PMC file measured on THESE kernel
+    sources; the CPU baseline knows physical cores from logical CPUs."""
+    import json
+    import os
+
+    import bench
+
+    h = bench.kernel_source_hash()
+    assert len(h) == 16 and int(h, 16) >= 0 and h == bench.kernel_source_hash()
+    cores, logical = bench.physical_cores()
+    assert 1 <= cores <= logical
+    profiles = tmp_path / "profiles"
+    profiles.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "kernel_source_hash", lambda: "feedfacefeedface")
+    monkeypatch.setattr(bench, "TRAFFIC_FILES", ("new.json", "old.json"))
+    (profiles / "old.json").write_text(json.dumps({"f16x3": {"hbm_bytes_per_launch": 1.0}}))  # no hash: a round-2 file
+    data, why = bench.load_traffic("f16x3")
+    assert data is None and "traffic not reported" in why and "None" in why
+    (profiles / "new.json").write_text(json.dumps({"kernel_source_hash": "0123456789abcdef", "f16x3": {"hbm_bytes_per_launch": 2.0}}))
+    data, why = bench.load_traffic("f16x3")
+    assert data is None and "0123456789abcdef" in why
+    (profiles / "new.json").write_text(json.dumps({"kernel_source_hash": "feedfacefeedface", "f16x3": {"hbm_bytes_per_launch": 3.0}}))
+    data, why = bench.load_traffic("f16x3")
+    assert data == {"hbm_bytes_per_launch": 3.0} and "new.json" in why and "feedfacefeedface" in why
+    assert bench.load_traffic("bf16") == (None, None) or bench.load_traffic("bf16")[0] is None
+    assert os.path.isdir(os.path.join(os.path.dirname(os.path.abspath(bench.__file__)), "allophant_amd", "csrc"))
