@@ -43,10 +43,12 @@ def shard_batch(batch: Batch, rank: int, world: int) -> Optional[Batch]:
 
 def gather_predictions(local: Optional[Predictions], names_and_classes: List[Tuple[str, int]], total_utterances: int,
                        device: torch.device, dst: int = 0, group=None,
-                       aliases: Optional[Dict[str, str]] = None) -> Optional[Predictions]:
+                       aliases: Optional[Dict[str, str]] = None, frames: Optional[int] = None) -> Optional[Predictions]:
     """Gathers per-rank ``Predictions`` to ``dst``: one ``gather`` of a packed ``[T_max, n_max, sum(C)]`` fp32 block per
     rank and one of the int64 frame lengths.  Returns the assembled ``Predictions`` ([T_max, N, C] per output, frames
-    beyond an utterance's length are zero) on ``dst`` and ``None`` elsewhere."""
+    beyond an utterance's length are zero) on ``dst`` and ``None`` elsewhere.  ``frames``: the padded frame count of the
+    global batch when the caller knows it (``spec.frame_lengths([L], spec)``): the ranks then need not agree on it with an
+    ``all_reduce`` whose result the host reads back."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     bounds = shard_bounds(total_utterances, world)
@@ -56,9 +58,14 @@ def gather_predictions(local: Optional[Predictions], names_and_classes: List[Tup
 
     # agree on the padded frame count (ranks may have different local max lengths)
     t_local = 0 if local is None else next(iter(local.outputs.values())).shape[0]
-    t_tensor = torch.tensor([t_local], dtype=torch.int64, device=device)
-    dist.all_reduce(t_tensor, op=dist.ReduceOp.MAX, group=group)
-    t_max = int(t_tensor.item())
+    if frames is not None:
+        if t_local > frames:
+            raise ValueError(f"a shard has {t_local} frames, more than the stated {frames} of the global batch")
+        t_max = int(frames)
+    else:
+        t_tensor = torch.tensor([t_local], dtype=torch.int64, device=device)
+        dist.all_reduce(t_tensor, op=dist.ReduceOp.MAX, group=group)
+        t_max = int(t_tensor.item())
 
     packed = torch.zeros(t_max, n_max, total_c, dtype=torch.float32, device=device)
     lengths = torch.zeros(n_max, dtype=torch.int64, device=device)
@@ -248,13 +255,16 @@ class DataParallelRunner:
 
 
 def gather_decoded(local: Optional[Decoded], names: List[str], total_utterances: int, device: torch.device, dst: int = 0,
-                   group=None) -> Optional[Dict[str, List[List[CTCHypothesis]]]]:
+                   group=None, capacity: Optional[int] = None) -> Optional[Dict[str, List[List[CTCHypothesis]]]]:
     """Gathers greedy CTC alignments instead of log-probabilities (only token ids cross xGMI).
     ``local`` is the shard's ``Estimator.greedy_decode_device`` result (``None`` for an empty shard), ``names`` the outputs
     to move (e.g. ``["phoneme"]``; run.py:767-774 decodes the phoneme output and, on request, attribute outputs).  One
     ``all_reduce(MAX)`` agrees on the longest alignment K, then ONE ``gather`` moves a packed int32 block per rank:
     ``[O, n_max]`` counts, ``[O, n_max]`` score bits, ``[O, n_max, K]`` tokens and ``[O, n_max, K]`` timesteps -- for config 3
-    and the phoneme output at most 4 x 2 x 499 x 4 B = 16 KB per rank against 1.4 MB of log-probabilities.  Returns, on ``dst``,
+    and the phoneme output at most 4 x 2 x 499 x 4 B = 16 KB per rank against 1.4 MB of log-probabilities.  With ``capacity``
+    (an alignment length no rank can exceed, e.g. the frame count of the global batch's padded length) the agreement -- an
+    ``all_reduce`` whose result the host reads back, i.e. a synchronisation with the step just enqueued -- is skipped and
+    every rank sends ``capacity`` slots per utterance: the call then only enqueues work.  Returns, on ``dst``,
     the hypotheses of the whole batch in the reference's form (per output, per utterance
     ``[CTCHypothesis(tokens, [], score, timesteps)]``); ``None`` elsewhere."""
     world = dist.get_world_size(group)
@@ -266,11 +276,14 @@ def gather_decoded(local: Optional[Decoded], names: List[str], total_utterances:
         local = local.select(names)
         if local.counts.shape[1] != bounds[rank][1] - bounds[rank][0]:
             raise ValueError("the local alignments do not cover this rank's block of utterances")
-    k_tensor = torch.zeros(1, dtype=torch.int32, device=device)
-    if local is not None and local.counts.numel():
-        k_tensor = local.counts.max().to(device=device, dtype=torch.int32).reshape(1)
-    dist.all_reduce(k_tensor, op=dist.ReduceOp.MAX, group=group)
-    k_max = int(k_tensor.item())
+    if capacity is not None:
+        k_max = int(capacity)
+    else:
+        k_tensor = torch.zeros(1, dtype=torch.int32, device=device)
+        if local is not None and local.counts.numel():
+            k_tensor = local.counts.max().to(device=device, dtype=torch.int32).reshape(1)
+        dist.all_reduce(k_tensor, op=dist.ReduceOp.MAX, group=group)
+        k_max = int(k_tensor.item())
 
     head = n_out * n_max
     packed = torch.zeros(2 * head + 2 * head * k_max, dtype=torch.int32, device=device)

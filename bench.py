@@ -512,8 +512,10 @@ def main():
         est = Estimator(spec, state, device, args.precision)
 
         def decoded_step():
+            # capacity = frames of the padded length: no rank can hold a longer alignment, so no per-step agreement (and no
+            # host read-back) is needed
             return parallel.gather_decoded(est.greedy_decode_device(est.predict(local, tfi, True)), ["phoneme"], n_global,
-                                           device, dst=0)
+                                           device, dst=0, capacity=w["frames_per_utt"])
 
         for _ in range(args.warmup):
             decoded_step()

@@ -47,6 +47,15 @@ def _worker(rank, world, port, result_path):
     names = [(n, c) for n, c in [("syllabic", 4), ("long", 4), ("phoneme", 7)]]
     gathered = data_parallel_predict(lambda b: _predict(spec, state, b, tfi), full, names, torch.device("cpu"), dst=0,
                                      aliases={"phone": "phoneme"})
+    # the same gather with the global frame count stated up front (no agreement round): identical tensors
+    shard = shard_batch(full, rank, world)
+    again = gather_predictions(_predict(spec, state, shard, tfi) if shard is not None else None, names, len(full),
+                               torch.device("cpu"), dst=0, aliases={"phone": "phoneme"},
+                               frames=S.frame_lengths([int(lengths.max())], spec)[0])
+    if rank == 0:
+        assert list(again.outputs) == list(gathered.outputs)
+        for name in again.outputs:
+            assert torch.equal(again.outputs[name], gathered.outputs[name]), name
     if rank == 0:
         torch.save({"outputs": gathered.outputs, "lengths": gathered.lengths}, result_path)
     else:
@@ -218,7 +227,7 @@ def _global_decoded(total, seed):
     return Decoded(["syllabic", "long", "phoneme"], tokens, timesteps, counts, scores)
 
 
-def _decoded_worker(rank, world, port, total, result_path):
+def _decoded_worker(rank, world, port, total, result_path, capacity=None):
     from allophant_amd.estimator import Decoded
     from allophant_amd.parallel import gather_decoded
 
@@ -230,7 +239,7 @@ def _decoded_worker(rank, world, port, total, result_path):
     local = None
     if hi > lo:
         local = Decoded(full.names, full.tokens[:, lo:hi], full.timesteps[:, lo:hi], full.counts[:, lo:hi], full.scores[:, lo:hi])
-    got = gather_decoded(local, ["phoneme", "long"], total, torch.device("cpu"), dst=0)
+    got = gather_decoded(local, ["phoneme", "long"], total, torch.device("cpu"), dst=0, capacity=capacity)
     if rank == 0:
         torch.save(got, result_path)
     else:
@@ -243,9 +252,9 @@ def test_two_rank_gather_of_decoded_alignments(tmp_path):
     """the data-parallel path can move greedy CTC alignments instead of log-probabilities.  Ragged shards
     (5 utterances -> 3 + 2) and an empty shard (1 utterance on 2 ranks) must reproduce the single-process hypotheses
     bit for bit, in utterance order, for the selected outputs only."""
-    for total in (5, 1):
-        result_path = str(tmp_path / f"decoded{total}.pt")
-        mp.spawn(_decoded_worker, args=(2, _free_port(), total, result_path), nprocs=2, join=True)
+    for total, capacity in ((5, None), (1, None), (5, 20), (1, 33)):  # with a capacity: no agreement round, same result
+        result_path = str(tmp_path / f"decoded{total}_{capacity}.pt")
+        mp.spawn(_decoded_worker, args=(2, _free_port(), total, result_path, capacity), nprocs=2, join=True)
         got = torch.load(result_path, weights_only=False)
         want = _global_decoded(total, seed=77).select(["phoneme", "long"]).hypotheses()
         assert list(got) == ["phoneme", "long"]
