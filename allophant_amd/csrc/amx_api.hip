@@ -1166,7 +1166,8 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     HIPCHK(h, hipEventRecord(h->pin_event[slot], s));
     h->pin_busy[slot] = true;
 
-    HIPCHK(h, hipMemsetAsync(h->nonfinite, 0, 4, s));  // amx_check_finite reports on THIS forward pass
+    // amx_check_finite reports on THIS forward pass; the slices of one over-long batch (AMX_FLAG_PADDED) add up
+    if (!(flags & AMX_FLAG_PADDED)) HIPCHK(h, hipMemsetAsync(h->nonfinite, 0, 4, s));
     // ---- input normalisation statistics + conv layer 0 (fused norm + conv + LN + GELU) ----
     { Timed t_(h, AMX_KC_OTHER); launch_audio_stats(d_audio, (const int64_t*)d_len, N, L, (double*)d_partial, (float*)d_stats, c.do_normalize, s); }
     { Timed t_(h, AMX_KC_CONV0); launch_conv0(prec, d_audio, (const int64_t*)d_len, (const float*)d_stats, N, L, (int)Ts[1], C, c.conv_kernel[0],
@@ -1459,6 +1460,7 @@ extern "C" int amx_check_finite(amx_handle h, void* stream, int64_t* frames) {
     HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
     int count = 0;
     HIPCHK(h, hipMemcpy(&count, h->nonfinite, 4, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemset(h->nonfinite, 0, 4));  // a check closes its reporting period
     if (frames) *frames = count;
     if (count > 0)
         return fail(h, AMX_ERANGE, std::to_string(count) + " valid frame(s) of the last forward pass hold non-finite logits: an activation left the "

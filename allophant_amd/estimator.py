@@ -330,6 +330,8 @@ class Estimator:
                 # utterances padded to the same L -- no operator mixes utterances, so the results are those of one call
                 if n_max < 1:
                     raise ValueError(f"utterances of {L} samples are too long for one forward pass")
+                # the slices add to one range-check count (`check_finite`): close the previous reporting period first
+                self._lib.amx_check_finite(self._handle, C.c_void_p(stream), None)
                 blocks = {d.offset: d.classes for d in descs}
                 for lo in range(0, N, n_max):
                     hi = min(N, lo + n_max)

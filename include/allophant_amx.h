@@ -170,7 +170,9 @@ int amx_synchronize(amx_handle h, void* stream);
  * planes of the fp16 modes hold |x| <= 65504; weights are packed under a per-tensor power-of-two scale, so only an
  * ACTIVATION (or a non-finite input sample) can leave that range, and it then reaches the logits as an infinity or a NaN.
  * Waits for `stream`, stores the number of valid frames with non-finite logits in *frames (may be NULL) and returns AMX_OK
- * when there are none, AMX_ERANGE otherwise (amx_last_error names the remedy: precision bf16x3 has the range of fp32). */
+ * when there are none, AMX_ERANGE otherwise (amx_last_error names the remedy: precision bf16x3 has the range of fp32).
+ * The count covers the last amx_forward; calls with AMX_FLAG_PADDED (slices of one batch) add to it instead of restarting
+ * it, and a check resets it. */
 int amx_check_finite(amx_handle h, void* stream, int64_t* frames);
 
 /* Replaces `GreedyCTCDecoder.__call__` (predictions.py:194-207), applied to every output of a prediction as the
