@@ -1266,16 +1266,42 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     const int64_t Mrows = packed ? Mp : Mpad;  // rows the layers work on
     const int64_t xp_plane = Mrows * D;
     const int64_t qk_plane = packed ? (int64_t)H * TpTot * 64 : (int64_t)N * H * Tp * 64;
+    // A residual product that launch_gemm cuts into K chunks (short batches) leaves its fix-up -- slab sum + bias + residual
+    // -> h -- to the LayerNorm that follows it: one kernel instead of the fix-up and a LayerNorm pass that re-reads h
+    // (AMX_NO_FUSED_FIXUP=1: developer A/B switch).
+    static const bool no_fused_fixup = getenv("AMX_NO_FUSED_FIXUP") && atoi(getenv("AMX_NO_FUSED_FIXUP")) != 0;
+    struct { bool on = false; GemmParams g; int splits = 0; } pending;
+    auto residual_gemm = [&](GemmParams& g, bool may_defer) {
+        g.splitk_ws = (float*)splitk;
+        g.splitk_ws_elems = splitk ? (int64_t)(SPLITK_BYTES / 4) : 0;
+        const int splits = may_defer && !no_fused_fixup ? gemm_planned_splits(prec, g) : 1;
+        if (splits > 1 && fixup_rownorm_eligible(g)) {
+            g.defer_fixup = 1;
+            pending.on = true;
+            pending.g = g;
+            pending.splits = splits;
+        }
+        { Timed t_(h, gemm_class(prec, g)); launch_gemm(prec, g, s); }
+    };
+    // LayerNorm of the residual stream (rows of hbuf) -> planes (and the fp32 rows, for the final one)
+    auto stream_norm = [&](const float* gamma, const float* beta, int64_t rows, int64_t plane, float* out_ln) {
+        Timed t_(h, AMX_KC_ROWNORM);
+        if (pending.on) {
+            launch_fixup_rownorm(prec, pending.g, pending.splits, gamma, beta, c.eps, xp, plane, D, out_ln, D, s);
+            pending.on = false;
+        } else {
+            launch_rownorm(prec, (const float*)hbuf, D, rows, D, gamma, beta, 0, nullptr, nullptr, c.eps, 0.f, xp, plane, D, out_ln, D, s);
+        }
+    };
     for (int l = 0; l < c.layers; ++l) {
         const Layer& ly = h->layers[l];
+        stream_norm(ly.ln1_g, ly.ln1_b, Mrows, xp_plane, nullptr);  // (completes the previous layer's FFN2 when that was deferred)
         if (saved[l]) {
             // a classifier reads hidden state l (OUTPUT_l, acoustic_model.py:478-483): padded layout; with packed rows the padded
             // frames take their pre-encoder rows (finite, as meaningless as any padded frame) and the valid ones are scattered in
             HIPCHK(h, hipMemcpyAsync(saved[l], packed ? hpad : hbuf, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s));
             if (packed) launch_pack_rows(saved[l], (float*)hbuf, (const int*)d_rowoff, (const int*)d_frames, N, T, D, true, s);
         }
-        { Timed t_(h, AMX_KC_ROWNORM); launch_rownorm(prec, (const float*)hbuf, D, Mrows, D, ly.ln1_g, ly.ln1_b, 0, nullptr, nullptr, c.eps, 0.f, xp, xp_plane, D,
-                       nullptr, 0, s); }
         {
             GemmParams g{};
             g.A = xp; g.a_plane = xp_plane; g.lda = D; g.rows_per_batch = Mrows;
@@ -1306,10 +1332,9 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             g.M = (int)Mrows; g.N = D; g.K = D;
             g.scale = ly.r_o; g.bias = ly.bo;
             g.residual = (const float*)hbuf; g.ldr = D; g.out_f32 = (float*)hbuf; g.ldo = D;
-            { Timed t_(h, gemm_class(prec, g)); run_gemm(prec, g, s); }
+            residual_gemm(g, true);
         }
-        { Timed t_(h, AMX_KC_ROWNORM); launch_rownorm(prec, (const float*)hbuf, D, Mrows, D, ly.ln2_g, ly.ln2_b, 0, nullptr, nullptr, c.eps, 0.f, xp, xp_plane, D,
-                       nullptr, 0, s); }
+        stream_norm(ly.ln2_g, ly.ln2_b, Mrows, xp_plane, nullptr);
         {
             GemmParams g{};
             g.A = xp; g.a_plane = xp_plane; g.lda = D; g.rows_per_batch = Mrows;
@@ -1326,7 +1351,8 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             g.M = (int)Mrows; g.N = D; g.K = F;
             g.scale = ly.r_2; g.bias = ly.b2;
             g.residual = (const float*)hbuf; g.ldr = D; g.out_f32 = (float*)hbuf; g.ldo = D;
-            { Timed t_(h, gemm_class(prec, g)); run_gemm(prec, g, s); }
+            // (the last layer of a packed batch is followed by the unpacking, not by a LayerNorm of these rows)
+            residual_gemm(g, !(packed && l == c.layers - 1));
         }
     }
     if (packed) {
@@ -1334,8 +1360,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         { Timed t_(h, AMX_KC_OTHER); launch_pack_rows((const float*)hpad, (float*)hpk, (const int*)d_rowoff, (const int*)d_frames, N, T, D, true, s); }
         hbuf = hpad;
     }
-    { Timed t_(h, AMX_KC_ROWNORM); launch_rownorm(prec, (const float*)hbuf, D, M, D, h->fln_g, h->fln_b, 0, nullptr, nullptr, c.eps, 0.f, xp, M * D, D,
-                   (float*)hfin, D, s); }
+    stream_norm(h->fln_g, h->fln_b, M, M * D, (float*)hfin);
 
     // ---- hierarchical projection ----
     const int E = c.embedding_size;

@@ -208,6 +208,9 @@ struct GemmParams {
     // the padding of one batch item are left out: neither computed nor stored); null: every tile
     const int* tile_list;  // tile index = first row / GEMM_LN_TILE_ROWS
     int n_tiles;
+    // set by a caller that will run the split-K fix-up itself (launch_fixup_rownorm: fused with the LayerNorm that follows the
+    // product): launch_gemm then writes the partial slabs only.  Only with gemm_planned_splits(...) > 1.
+    int defer_fixup;
     unsigned long long* stamps;  // developer diagnostic (-DAMX_PP_STAMP builds of tools/gemm_bench.hip), else null
 };
 
@@ -217,6 +220,15 @@ void launch_gemm(int prec, const GemmParams& p, hipStream_t stream);
 bool gemm_uses_pp(int prec, const GemmParams& p);
 // true when a product with ln_gamma / ln_beta set can run on the row-complete kernel with fused LayerNorm + GELU
 bool gemm_fuses_ln(int prec, const GemmParams& p);
+// K chunks launch_gemm will cut this product into (1: no split-K, no fix-up launch); `p` as it will be passed to launch_gemm,
+// split-K workspace included
+int gemm_planned_splits(int prec, const GemmParams& p);
+// the fix-up of a product launched with defer_fixup, fused with the LayerNorm of the rows it completes: p.out_f32 (the
+// residual stream, N = row width <= 1024, N % 4 == 0) gets scale * sum of slabs + bias + residual, and LayerNorm(gamma, beta,
+// eps) of those rows goes to the planes out_p (may be null) and to out_ln (fp32, may be null)
+bool fixup_rownorm_eligible(const GemmParams& p);
+void launch_fixup_rownorm(int prec, const GemmParams& p, int splits, const float* gamma, const float* beta, float eps, void* out_p,
+                          int64_t out_plane, int64_t ldp, float* out_ln, int64_t ldo_ln, hipStream_t stream);
 // same kernel with grid.z = groups (per-group pointer advances za/zw/zbias/zout/zoutp); requires N <= 64
 void launch_gemm_grouped(int prec, const GemmParams& p, int groups, hipStream_t stream);
 

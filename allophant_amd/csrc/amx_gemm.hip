@@ -158,7 +158,7 @@ void launch_pp_tiles(const GemmParams& p, int splits, hipStream_t stream) {
     dim3 grid(units < cus ? units : cus, 1, 1);  // persistent: one 128-KiB-LDS workgroup per CU
     if (splits > 1) {
         hipLaunchKernelGGL((gemm_pp_kernel<T, NT, MI>), grid, dim3(512), pp::LDS_BYTES, stream, split_view(p, splits));
-        launch_fixup<T, NT>(p, splits, stream);
+        if (!p.defer_fixup) launch_fixup<T, NT>(p, splits, stream);
     } else {
         hipLaunchKernelGGL((gemm_pp_kernel<T, NT, MI>), grid, dim3(512), pp::LDS_BYTES, stream, p);
     }
@@ -279,7 +279,7 @@ void launch_gemm_t(const GemmParams& p, hipStream_t stream) {
             q.zbias = q.zoutp = 0;
         }
         launch_gemm_dma_shape<T, NT>(shape, q, splits, stream);
-        if (splits > 1) launch_fixup<T, NT>(p, splits, stream);
+        if (splits > 1 && !p.defer_fixup) launch_fixup<T, NT>(p, splits, stream);
         return;
     }
     // narrow outputs (grouped pos-conv, small classifier heads) use the 128x64 tile
@@ -299,7 +299,33 @@ void launch_gemm_t(const GemmParams& p, hipStream_t stream) {
     const size_t lds = (size_t)NT * (BM + BN) * 128;
     if (narrow) hipLaunchKernelGGL((gemm_kernel<T, NT, 128, 64, 4, 1>), grid, dim3(256), lds, stream, q);
     else hipLaunchKernelGGL((gemm_kernel<T, NT, 128, 128, 2, 2>), grid, dim3(256), lds, stream, q);
-    if (splits > 1) launch_fixup<T, NT>(p, splits, stream);
+    if (splits > 1 && !p.defer_fixup) launch_fixup<T, NT>(p, splits, stream);
+}
+
+// the K chunks launch_gemm_t will use: the same decisions, without the launches
+int planned_splits(int NT, const GemmParams& p) {
+    if (!dma_preferred_shape(NT, p) && pp_eligible(NT, p)) {
+        int mi, splits;
+        pp_plan(NT, p, &mi, &splits);
+        return splits;
+    }
+    const int shape = dma_tile_shape(NT, p, 1);
+    if (shape) {
+        const int bm = shape == 2 ? 64 : 128, bn = shape == 2 ? 32 : 64;
+        const int tiles = ((p.N + bn - 1) / bn) * ((p.M + bm - 1) / bm);
+        return p.K >= 4096 ? choose_splits(p, tiles, device_cus() / 2, BK, 16 * BK) : 1;
+    }
+    const int BN = p.N <= 64 ? 64 : 128;
+    const int tiles = ((p.N + BN - 1) / BN) * ((p.M + 127) / 128);
+    return choose_splits(p, tiles, device_cus() / 4, BK, 2 * BK);
+}
+
+template <typename T, int NT>
+void launch_fixup_rownorm_t(const GemmParams& p, int splits, const float* gamma, const float* beta, float eps, void* out_p,
+                            int64_t out_plane, int64_t ldp, float* out_ln, int64_t ldo_ln, hipStream_t stream) {
+    dim3 grid((unsigned)((p.M + 3) / 4));
+    hipLaunchKernelGGL((splitk_fixup_rownorm_kernel<T, NT>), grid, dim3(256), 0, stream, p, (const float*)p.splitk_ws, splits,
+                       (int64_t)p.M * p.N, gamma, beta, eps, (T*)out_p, out_plane, ldp, out_ln, ldo_ln);
 }
 
 template <typename T, int NT>
@@ -332,6 +358,28 @@ bool gemm_uses_pp(int prec, const GemmParams& p_in) {
     const GemmParams p = with_vec_flag(p_in);
     const int NT = prec_planes(prec);
     return pp_eligible(NT, p) && !dma_preferred_shape(NT, p);  // the routing of launch_gemm_t
+}
+
+int gemm_planned_splits(int prec, const GemmParams& p_in) {
+    const GemmParams p = with_vec_flag(p_in);
+    if (p.ln_gamma) return 1;
+    return planned_splits(prec_planes(prec), p);
+}
+
+bool fixup_rownorm_eligible(const GemmParams& p) {
+    return p.splitk_ws && p.out_f32 && !p.out_p && p.act == 0 && p.mode == 0 && !p.row_len && !p.ln_gamma && p.N % 4 == 0 &&
+           p.N <= 1024 && p.ldo % 4 == 0 && (!p.residual || p.ldr % 4 == 0) && !((uintptr_t)p.out_f32 & 15) &&
+           !((uintptr_t)p.residual & 15) && !((uintptr_t)p.bias & 15) && p.zout == 0;
+}
+
+void launch_fixup_rownorm(int prec, const GemmParams& p, int splits, const float* gamma, const float* beta, float eps, void* out_p,
+                          int64_t out_plane, int64_t ldp, float* out_ln, int64_t ldo_ln, hipStream_t stream) {
+    switch (prec) {
+        case PREC_BF16: launch_fixup_rownorm_t<bf16, 1>(p, splits, gamma, beta, eps, out_p, out_plane, ldp, out_ln, ldo_ln, stream); break;
+        case PREC_F16: launch_fixup_rownorm_t<f16, 1>(p, splits, gamma, beta, eps, out_p, out_plane, ldp, out_ln, ldo_ln, stream); break;
+        case PREC_BF16X3: launch_fixup_rownorm_t<bf16, 2>(p, splits, gamma, beta, eps, out_p, out_plane, ldp, out_ln, ldo_ln, stream); break;
+        default: launch_fixup_rownorm_t<f16, 2>(p, splits, gamma, beta, eps, out_p, out_plane, ldp, out_ln, ldo_ln, stream); break;
+    }
 }
 
 void launch_gemm(int prec, const GemmParams& p_in, hipStream_t stream) {
