@@ -56,6 +56,10 @@ struct amx_handle_s {
     std::vector<amx_class_desc> classes;
     std::vector<int> order;
     int prec = AMX_PREC_F16X3, NT = 2;
+    // two-plane modes: GEMM operands as interleaved planes (amx_common.h pidx(): hi and lo of 32 K elements share a 128-byte
+    // line, which is what the ping-pong GEMM's whole-line operand DMA needs).  Needs 32-element row blocks: conv_dim and ffn
+    // multiples of 32 (every wav2vec 2.0 shape); other shapes keep separate planes and run on the generic tile kernels.
+    bool il = true;
     std::string err;
     std::vector<void*> allocs;
     int64_t weight_bytes = 0, ws_bytes = 0;
@@ -301,7 +305,8 @@ static int pack_linear(amx_handle h, const TensorMap& tm, const std::string& key
         return fail(h, AMX_EINVAL, "tensor " + key + " has " + std::to_string(t->numel) + " elements, expected " +
                                        std::to_string((int64_t)rows * cols));
     HIPCHK(h, hipMemcpy(staging, t->data, (size_t)t->numel * 4, hipMemcpyHostToDevice));
-    launch_pack_matrix(h->prec, staging, rows, cols, cols, 1, scale, (char*)dst + (size_t)row0 * ldd * 2, plane, ldd, cols_pad, 0);
+    launch_pack_matrix(h->prec, staging, rows, cols, cols, 1, scale, (char*)dst + (size_t)row0 * ldd * 2 * (plane == PLANE_IL ? 2 : 1), plane, ldd,
+                       cols_pad, 0);
     HIPCHK(h, hipDeviceSynchronize());
     return AMX_OK;
 }
@@ -327,8 +332,15 @@ static float pack_scale(std::initializer_list<std::pair<const amx_tensor*, float
     return pow2_for(m);
 }
 
+// plane distance of a GEMM operand / row-stride granule of its padded K: interleaved (PLANE_IL, 32) or separate planes
+// (a separate plane is never exactly PLANE_IL elements away: tiny matrices get a distance of 64, and every plane buffer is
+// allocated with PLANE_SLACK bytes to spare for it)
+constexpr size_t PLANE_SLACK = 256;
+static int64_t pln(amx_handle h, int64_t separate) { return h->il ? PLANE_IL : std::max<int64_t>(separate, 64); }
+static int kalign(amx_handle h) { return h->il ? 32 : 8; }
+
 static void* alloc_planes(amx_handle h, int64_t elems_per_plane) {
-    return dev_alloc(h, (size_t)elems_per_plane * 2 * h->NT);
+    return dev_alloc(h, (size_t)elems_per_plane * 2 * h->NT + PLANE_SLACK);
 }
 
 extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, const amx_class_desc* classes, int n_classes,
@@ -361,6 +373,10 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
     h->cfg = *cfg;
     h->prec = cfg->precision;
     h->NT = prec_planes(cfg->precision);
+    {
+        static const bool plain = getenv("AMX_PLAIN_PLANES") && atoi(getenv("AMX_PLAIN_PLANES")) != 0;  // developer A/B switch
+        h->il = h->NT > 1 && !plain && cfg->conv_dim % 32 == 0 && cfg->ffn % 32 == 0;
+    }
     h->classes.assign(classes, classes + n_classes);
     auto bail = [&](int code) {
         g_create_error = h->err;
@@ -437,7 +453,7 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
                 if (hipMemcpy(staging, t->data, (size_t)t->numel * 4, hipMemcpyHostToDevice) != hipSuccess) { h->err = "H2D failed"; return bail(AMX_EHIP); }
                 const float ps = pack_scale({{t, 1.f}});
                 h->conv_r[i] = 1.f / ps;
-                launch_pack_conv_w(h->prec, staging, C, c_in, k, ps, h->conv_w[i], plane, 0);
+                launch_pack_conv_w(h->prec, staging, C, c_in, k, ps, h->conv_w[i], pln(h, plane), 0);
                 if (hipDeviceSynchronize() != hipSuccess) { h->err = "pack_conv_w failed"; return bail(AMX_EHIP); }
             }
             c_in = C;
@@ -453,7 +469,7 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
         if (!h->fp_w) { h->err = "device allocation failed"; return bail(AMX_ENOMEM); }
         const float ps = pack_scale({{tm.get(p + "projection.weight"), 1.f}});
         h->fp_r = 1.f / ps;
-        TRY(pack_linear(h, tm, p + "projection.weight", D, C, ps, h->fp_w, (int64_t)D * C, C, 0, C, staging));
+        TRY(pack_linear(h, tm, p + "projection.weight", D, C, ps, h->fp_w, pln(h, (int64_t)D * C), C, 0, C, staging));
     }
     // ---- positional conv (weight-norm folded) ----
     {
@@ -515,7 +531,7 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
         ly.r_qkv = 1.f / ps_qkv;
         for (int j = 0; j < 3; ++j) {
             float sc = j == 0 ? qscale : 1.f;
-            TRY(pack_linear(h, tm, p + "attention." + names[j] + ".weight", D, D, sc * ps_qkv, ly.wqkv, (int64_t)3 * D * D, D, j * D, D, staging));
+            TRY(pack_linear(h, tm, p + "attention." + names[j] + ".weight", D, D, sc * ps_qkv, ly.wqkv, pln(h, (int64_t)3 * D * D), D, j * D, D, staging));
             const amx_tensor* b = tm.get(p + "attention." + names[j] + ".bias");
             if (!b || b->numel != D) { h->err = "missing tensor " + p + "attention." + names[j] + ".bias"; return bail(AMX_EINVAL); }
             if (hipMemcpy(staging, b->data, (size_t)D * 4, hipMemcpyHostToDevice) != hipSuccess) { h->err = "H2D failed"; return bail(AMX_EHIP); }
@@ -526,11 +542,11 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
         const float ps_1 = pack_scale({{tm.get(p + "feed_forward.intermediate_dense.weight"), 1.f}});
         const float ps_2 = pack_scale({{tm.get(p + "feed_forward.output_dense.weight"), 1.f}});
         ly.r_o = 1.f / ps_o; ly.r_1 = 1.f / ps_1; ly.r_2 = 1.f / ps_2;
-        TRY(pack_linear(h, tm, p + "attention.out_proj.weight", D, D, ps_o, ly.wo, (int64_t)D * D, D, 0, D, staging));
+        TRY(pack_linear(h, tm, p + "attention.out_proj.weight", D, D, ps_o, ly.wo, pln(h, (int64_t)D * D), D, 0, D, staging));
         TRY(upload_f32(h, tm, p + "attention.out_proj.bias", D, &ly.bo));
-        TRY(pack_linear(h, tm, p + "feed_forward.intermediate_dense.weight", F, D, ps_1, ly.w1, (int64_t)F * D, D, 0, D, staging));
+        TRY(pack_linear(h, tm, p + "feed_forward.intermediate_dense.weight", F, D, ps_1, ly.w1, pln(h, (int64_t)F * D), D, 0, D, staging));
         TRY(upload_f32(h, tm, p + "feed_forward.intermediate_dense.bias", F, &ly.b1));
-        TRY(pack_linear(h, tm, p + "feed_forward.output_dense.weight", D, F, ps_2, ly.w2, (int64_t)D * F, F, 0, F, staging));
+        TRY(pack_linear(h, tm, p + "feed_forward.output_dense.weight", D, F, ps_2, ly.w2, pln(h, (int64_t)D * F), F, 0, F, staging));
         TRY(upload_f32(h, tm, p + "feed_forward.output_dense.bias", D, &ly.b2));
     }
     TRY(upload_f32(h, tm, AM + "encoder.layer_norm.weight", D, &h->fln_g));
@@ -568,12 +584,12 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
         st.classes = {ci};
         st.direct_output = direct;
         st.K = K;
-        st.Kpad = round_up(K, 8);
+        st.Kpad = round_up(K, kalign(h));
         st.rows = c.out_features;
         st.composed = composed;
         st.parts_dev = nullptr;
         st.time_heads = c.time_heads;
-        st.Cpad = round_up(c.out_features, 8);
+        st.Cpad = round_up(c.out_features, kalign(h));
         if (!direct) {
             int colp = 0;
             for (int d = 0; d < c.n_deps; ++d) {
@@ -620,8 +636,8 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
                 const float ps_in = pack_scale({{tm.get(p + "attention.in_proj_weight"), 1.f}});
                 const float ps_out = pack_scale({{tm.get(p + "attention.out_proj.weight"), 1.f}});
                 st.r_tin = 1.f / ps_in; st.r_tout = 1.f / ps_out;
-                TRY(pack_linear(h, tm, p + "attention.in_proj_weight", 3 * Co, Co, ps_in, st.tl_win, plane_in, st.Cpad, 0, st.Cpad, staging));
-                TRY(pack_linear(h, tm, p + "attention.out_proj.weight", Co, Co, ps_out, st.tl_wout, plane_out, st.Cpad, 0, st.Cpad, staging));
+                TRY(pack_linear(h, tm, p + "attention.in_proj_weight", 3 * Co, Co, ps_in, st.tl_win, pln(h, plane_in), st.Cpad, 0, st.Cpad, staging));
+                TRY(pack_linear(h, tm, p + "attention.out_proj.weight", Co, Co, ps_out, st.tl_wout, pln(h, plane_out), st.Cpad, 0, st.Cpad, staging));
                 TRY(upload_f32(h, tm, p + "attention.in_proj_bias", 3 * Co, &st.tl_bin));
                 TRY(upload_f32(h, tm, p + "attention.out_proj.bias", Co, &st.tl_bout));
                 TRY(upload_f32(h, tm, p + "layer_norm.weight", Co, &st.tl_g));
@@ -642,7 +658,7 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
                 }
                 p += "input_projection.";
             }
-            TRY(pack_linear(h, tm, p + "weight", c.out_features, st.K, ps_w, st.W, (int64_t)st.rows * st.Kpad, st.Kpad, row0, st.Kpad, staging));
+            TRY(pack_linear(h, tm, p + "weight", c.out_features, st.K, ps_w, st.W, pln(h, (int64_t)st.rows * st.Kpad), st.Kpad, row0, st.Kpad, staging));
             const amx_tensor* b = tm.get(p + "bias");
             if (!b || b->numel != c.out_features) { h->err = "missing tensor " + p + "bias"; return bail(AMX_EINVAL); }
             if (hipMemcpy(st.bias + row0, b->data, (size_t)c.out_features * 4, hipMemcpyHostToDevice) != hipSuccess) { h->err = "H2D failed"; return bail(AMX_EHIP); }
@@ -784,7 +800,7 @@ static int install_inventory(amx_handle h, std::vector<int64_t>&& key, const std
         return fail_free(AMX_EHIP, "inventory table upload failed");
     if (P1 > 0) {
         if (hipMalloc((void**)&e.idx_dev, idx.size() * 8) != hipSuccess ||
-            hipMalloc(&e.composed_w, (size_t)P1 * E * 2 * h->NT) != hipSuccess ||
+            hipMalloc(&e.composed_w, (size_t)P1 * round_up(E, kalign(h)) * 2 * h->NT + PLANE_SLACK) != hipSuccess ||
             hipMalloc((void**)&e.composed_f32, (size_t)P1 * E * 4) != hipSuccess)
             return fail_free(AMX_ENOMEM, "inventory allocation failed");
         if (hipMemcpyAsync(e.idx_dev, idx.data(), idx.size() * 8, hipMemcpyHostToDevice, s) != hipSuccess)
@@ -802,7 +818,10 @@ static int install_inventory(amx_handle h, std::vector<int64_t>&& key, const std
                 }
             const float ps = pow2_for(m);
             e.r_composed = 1.f / ps;
-            launch_compose(h->prec, h->emb, E, e.idx_dev, P1, features, ps, e.composed_f32, e.composed_w, (int64_t)P1 * E, E, s);
+            const int Eld = round_up(E, kalign(h));  // row stride of the planes; the pad columns are never read (K = E)
+            if (Eld != E && hipMemsetAsync(e.composed_w, 0, (size_t)P1 * Eld * 2 * h->NT, s) != hipSuccess)
+                return fail_free(AMX_EHIP, "inventory upload failed");
+            launch_compose(h->prec, h->emb, E, e.idx_dev, P1, features, ps, e.composed_f32, e.composed_w, pln(h, (int64_t)P1 * Eld), Eld, s);
         }
         if (hipGetLastError() != hipSuccess) return fail_free(AMX_EHIP, "compose kernel launch failed");
     }
@@ -1058,18 +1077,18 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     WS("rowoff", (size_t)(2 * N + 1) * 4, d_rowoff);
     WS("partial", (size_t)N * 64 * 3 * 8, d_partial);
     WS("stats", (size_t)N * 2 * 4, d_stats);
-    WS("actA", (size_t)rows1 * C * 2 * NT, actA);
-    WS("actB", (size_t)rows2 * C * 2 * NT, actB);
+    WS("actA", (size_t)rows1 * C * 2 * NT + PLANE_SLACK, actA);
+    WS("actB", (size_t)rows2 * C * 2 * NT + PLANE_SLACK, actB);
     WS("preln", (size_t)rows2 * C * 4, preln);
     WS("h", (size_t)M * D * 4, hbuf);
-    WS("xp", (size_t)M * D * 2 * NT, xp);
+    WS("xp", (size_t)M * D * 2 * NT + PLANE_SLACK, xp);
     WS("hg", (size_t)N * Tpad * D * 2 * NT, hg);
     const size_t qkv_bytes = (size_t)N * H * Tp * 64 * 2 * NT;
     if ((rc = ws_get(h, "q", qkv_bytes, &qb, true))) return rc;
     if ((rc = ws_get(h, "k", qkv_bytes, &kb, true))) return rc;
     if ((rc = ws_get(h, "vt", qkv_bytes, &vtb, true))) return rc;
-    WS("ao", (size_t)M * D * 2 * NT, ao);
-    WS("ff", (size_t)M * F * 2 * NT, ff);
+    WS("ao", (size_t)M * D * 2 * NT + PLANE_SLACK, ao);
+    WS("ff", (size_t)M * F * 2 * NT + PLANE_SLACK, ff);
     WS("hfin", (size_t)M * D * 4, hfin);
     WS("logits", (size_t)M * h->ld_logits * 4, logits);
     // Packed rows: a ragged batch runs its encoder layers on the valid frames only (rows of utterance n at row_off[n], all
@@ -1172,17 +1191,17 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     { Timed t_(h, AMX_KC_OTHER); launch_audio_stats(d_audio, (const int64_t*)d_len, N, L, (double*)d_partial, (float*)d_stats, c.do_normalize, s); }
     { Timed t_(h, AMX_KC_CONV0); launch_conv0(prec, d_audio, (const int64_t*)d_len, (const float*)d_stats, N, L, (int)Ts[1], C, c.conv_kernel[0],
                  c.conv_stride[0], h->c0_w, h->conv_b[0], h->conv_g[0], h->conv_be[0], 1e-5f, c.do_normalize, actA,
-                 rows1 * C, ragged ? 1 : 0, s); }
+                 pln(h, rows1 * C), ragged ? 1 : 0, s); }
     // ---- conv layers 1..n-1: implicit GEMM over overlapping channels-last windows, then LN + GELU rows ----
     void* cur = actA;
-    int64_t cur_plane = rows1 * C;
+    int64_t cur_plane = pln(h, rows1 * C);
     void* other = actB;
     for (int i = 1; i < c.n_conv; ++i) {
         const int64_t rows_out = (int64_t)N * Ts[i + 1];
         GemmParams g{};
         g.A = cur; g.a_plane = cur_plane; g.lda = (int64_t)c.conv_stride[i] * C; g.rows_per_batch = Ts[i + 1];
         g.a_batch_stride = Ts[i] * C;
-        g.W = h->conv_w[i]; g.w_plane = (int64_t)C * C * c.conv_kernel[i]; g.ldw = (int64_t)C * c.conv_kernel[i];
+        g.W = h->conv_w[i]; g.w_plane = pln(h, (int64_t)C * C * c.conv_kernel[i]); g.ldw = (int64_t)C * c.conv_kernel[i];
         g.M = (int)rows_out; g.N = C; g.K = C * c.conv_kernel[i];
         g.scale = h->conv_r[i]; g.bias = h->conv_b[i];
         if (ragged) {  // honoured by the row-complete kernel only
@@ -1190,7 +1209,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             g.n_tiles = (int)(tile_first[i + 1] - tile_first[i]);
         }
         const bool last = i == c.n_conv - 1;
-        const int64_t out_plane = rows_out * C;
+        const int64_t out_plane = pln(h, rows_out * C);
         if (!last) {
             // LayerNorm + GELU fused into the GEMM epilogue when the row-complete kernel takes the shape (C == 512)
             GemmParams f = g;
@@ -1227,7 +1246,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     {
         GemmParams g{};
         g.A = cur; g.a_plane = cur_plane; g.lda = C; g.rows_per_batch = M; g.a_batch_stride = 0;
-        g.W = h->fp_w; g.w_plane = (int64_t)D * C; g.ldw = C;
+        g.W = h->fp_w; g.w_plane = pln(h, (int64_t)D * C); g.ldw = C;
         g.M = (int)M; g.N = D; g.K = C;
         g.scale = h->fp_r; g.bias = h->fp_bias;
         g.row_len = (const int*)d_frames; g.rows_T = T;
@@ -1264,7 +1283,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         hbuf = hpk;
     }
     const int64_t Mrows = packed ? Mp : Mpad;  // rows the layers work on
-    const int64_t xp_plane = Mrows * D;
+    const int64_t xp_plane = pln(h, Mrows * D);
     const int64_t qk_plane = packed ? (int64_t)H * TpTot * 64 : (int64_t)N * H * Tp * 64;
     // A residual product that launch_gemm cuts into K chunks (short batches) leaves its fix-up -- slab sum + bias + residual
     // -> h -- to the LayerNorm that follows it: one kernel instead of the fix-up and a LayerNorm pass that re-reads h
@@ -1305,7 +1324,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         {
             GemmParams g{};
             g.A = xp; g.a_plane = xp_plane; g.lda = D; g.rows_per_batch = Mrows;
-            g.W = ly.wqkv; g.w_plane = (int64_t)3 * D * D; g.ldw = D;
+            g.W = ly.wqkv; g.w_plane = pln(h, (int64_t)3 * D * D); g.ldw = D;
             g.M = (int)Mrows; g.N = 3 * D; g.K = D;
             g.scale = ly.r_qkv; g.bias = ly.bqkv;
             g.mode = 1; g.q = qb; g.k = kb; g.v = vtb;
@@ -1328,7 +1347,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         {
             GemmParams g{};
             g.A = ao; g.a_plane = xp_plane; g.lda = D; g.rows_per_batch = Mrows;
-            g.W = ly.wo; g.w_plane = (int64_t)D * D; g.ldw = D;
+            g.W = ly.wo; g.w_plane = pln(h, (int64_t)D * D); g.ldw = D;
             g.M = (int)Mrows; g.N = D; g.K = D;
             g.scale = ly.r_o; g.bias = ly.bo;
             g.residual = (const float*)hbuf; g.ldr = D; g.out_f32 = (float*)hbuf; g.ldo = D;
@@ -1338,16 +1357,16 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         {
             GemmParams g{};
             g.A = xp; g.a_plane = xp_plane; g.lda = D; g.rows_per_batch = Mrows;
-            g.W = ly.w1; g.w_plane = (int64_t)F * D; g.ldw = D;
+            g.W = ly.w1; g.w_plane = pln(h, (int64_t)F * D); g.ldw = D;
             g.M = (int)Mrows; g.N = F; g.K = D;
             g.scale = ly.r_1; g.bias = ly.b1; g.act = 1;
-            g.out_p = ff; g.out_plane = Mrows * F; g.ldp = F;
+            g.out_p = ff; g.out_plane = pln(h, Mrows * F); g.ldp = F;
             { Timed t_(h, gemm_class(prec, g)); run_gemm(prec, g, s); }
         }
         {
             GemmParams g{};
-            g.A = ff; g.a_plane = Mrows * F; g.lda = F; g.rows_per_batch = Mrows;
-            g.W = ly.w2; g.w_plane = (int64_t)D * F; g.ldw = F;
+            g.A = ff; g.a_plane = pln(h, Mrows * F); g.lda = F; g.rows_per_batch = Mrows;
+            g.W = ly.w2; g.w_plane = pln(h, (int64_t)D * F); g.ldw = F;
             g.M = (int)Mrows; g.N = D; g.K = F;
             g.scale = ly.r_2; g.bias = ly.b2;
             g.residual = (const float*)hbuf; g.ldr = D; g.out_f32 = (float*)hbuf; g.ldo = D;
@@ -1360,15 +1379,16 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         { Timed t_(h, AMX_KC_OTHER); launch_pack_rows((const float*)hpad, (float*)hpk, (const int*)d_rowoff, (const int*)d_frames, N, T, D, true, s); }
         hbuf = hpad;
     }
-    stream_norm(h->fln_g, h->fln_b, M, M * D, (float*)hfin);
+    stream_norm(h->fln_g, h->fln_b, M, pln(h, M * D), (float*)hfin);
 
     // ---- hierarchical projection ----
     const int E = c.embedding_size;
     void *ebuf = nullptr, *cat = nullptr;
     int kcat = 0;
     for (auto& st : h->steps) kcat = std::max(kcat, st.direct_output ? 0 : st.Kpad);
-    if (E > 0) WS("e", (size_t)M * E * 2 * NT, ebuf);
-    if (kcat > 0) WS("cat", (size_t)M * kcat * 2 * NT, cat);
+    const int Eld = round_up(E, kalign(h));  // row stride of the embedding planes (pad columns are never read: K = E)
+    if (E > 0) WS("e", (size_t)M * Eld * 2 * NT + PLANE_SLACK, ebuf);
+    if (kcat > 0) WS("cat", (size_t)M * kcat * 2 * NT + PLANE_SLACK, cat);
     void *tl_x = nullptr, *tl_p = nullptr, *tl_qkv = nullptr;
     {
         int cmax = 0;
@@ -1380,14 +1400,14 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             }
         if (cmax > 0) {
             WS("tl_x", (size_t)M * cmax * 4, tl_x);
-            WS("tl_p", (size_t)M * cmax * 2 * NT, tl_p);
+            WS("tl_p", (size_t)M * cmax * 2 * NT + PLANE_SLACK, tl_p);
             WS("tl_qkv", (size_t)M * cmax * 3 * 4, tl_qkv);
         }
     }
     const bool blanks = c.dependency_blanks != 0;
     for (auto& st : h->steps) {
         const void* A = xp;
-        int64_t a_plane = M * D, lda = D;
+        int64_t a_plane = pln(h, M * D), lda = D;
         if (!st.direct_output) {
             for (size_t i = 0; i < st.parts.size(); ++i) {
                 int dep = st.part_dep[i];
@@ -1410,13 +1430,13 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
                 HIPCHK(h, hipStreamSynchronize(s));
                 st.parts_uploaded = st.parts;
             }
-            { Timed t_(h, AMX_KC_OTHER); launch_concat(prec, st.parts_dev, (int)st.parts.size(), (const float*)logits, h->ld_logits, M, cat, M * st.Kpad,
-                          st.Kpad, st.Kpad, s); }
-            A = cat; a_plane = M * st.Kpad; lda = st.Kpad;
+            { Timed t_(h, AMX_KC_OTHER); launch_concat(prec, st.parts_dev, (int)st.parts.size(), (const float*)logits, h->ld_logits, M, cat,
+                          pln(h, M * st.Kpad), st.Kpad, st.Kpad, s); }
+            A = cat; a_plane = pln(h, M * st.Kpad); lda = st.Kpad;
         }
         GemmParams g{};
         g.A = A; g.a_plane = a_plane; g.lda = lda; g.rows_per_batch = M;
-        g.W = st.W; g.w_plane = (int64_t)st.rows * st.Kpad; g.ldw = st.Kpad;
+        g.W = st.W; g.w_plane = pln(h, (int64_t)st.rows * st.Kpad); g.ldw = st.Kpad;
         g.M = (int)M; g.N = st.rows; g.K = st.Kpad;
         g.scale = st.r_w; g.bias = st.bias;
         if (st.time_heads > 0) {
@@ -1425,30 +1445,30 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             g.out_f32 = (float*)tl_x; g.ldo = Co;
             { Timed t_(h, gemm_class(prec, g)); run_gemm(prec, g, s); }
             { Timed t_(h, AMX_KC_OTHER); launch_time_ln_pe(prec, (const float*)tl_x, M, Co, T, st.tl_g, st.tl_b, 1e-5f, st.tl_pe, tl_p,
-                              M * Cp, Cp, s); }
+                              pln(h, M * Cp), Cp, s); }
             GemmParams gi{};
-            gi.A = tl_p; gi.a_plane = M * Cp; gi.lda = Cp; gi.rows_per_batch = M;
-            gi.W = st.tl_win; gi.w_plane = (int64_t)3 * Co * Cp; gi.ldw = Cp;
+            gi.A = tl_p; gi.a_plane = pln(h, M * Cp); gi.lda = Cp; gi.rows_per_batch = M;
+            gi.W = st.tl_win; gi.w_plane = pln(h, (int64_t)3 * Co * Cp); gi.ldw = Cp;
             gi.M = (int)M; gi.N = 3 * Co; gi.K = Cp;
             gi.scale = st.r_tin; gi.bias = st.tl_bin;
             gi.out_f32 = (float*)tl_qkv; gi.ldo = 3 * Co;
             { Timed t_(h, gemm_class(prec, gi)); run_gemm(prec, gi, s); }
             { Timed t_(h, AMX_KC_OTHER); launch_time_attention(prec, (const float*)tl_qkv, (const int*)d_frames, N, T, Co, st.time_heads,
-                                  tl_p, M * Cp, Cp, s); }
+                                  tl_p, pln(h, M * Cp), Cp, s); }
             // out_proj lands where the plain linear classifier would have written
             g = GemmParams{};
-            g.A = tl_p; g.a_plane = M * Cp; g.lda = Cp; g.rows_per_batch = M;
-            g.W = st.tl_wout; g.w_plane = (int64_t)Co * Cp; g.ldw = Cp;
+            g.A = tl_p; g.a_plane = pln(h, M * Cp); g.lda = Cp; g.rows_per_batch = M;
+            g.W = st.tl_wout; g.w_plane = pln(h, (int64_t)Co * Cp); g.ldw = Cp;
             g.M = (int)M; g.N = Co; g.K = Cp;
             g.scale = st.r_tout; g.bias = st.tl_bout;
         }
         if (st.composed) {
-            g.out_p = ebuf; g.out_plane = M * E; g.ldp = E;
+            g.out_p = ebuf; g.out_plane = pln(h, M * Eld); g.ldp = Eld;
             { Timed t_(h, gemm_class(prec, g)); run_gemm(prec, g, s); }
             // logits = (e @ composed) / sqrt(E)   (acoustic_model.py:234)
             GemmParams g2{};
-            g2.A = ebuf; g2.a_plane = M * E; g2.lda = E; g2.rows_per_batch = M;
-            g2.W = h->composed_w; g2.w_plane = (int64_t)h->P1 * E; g2.ldw = E;
+            g2.A = ebuf; g2.a_plane = pln(h, M * Eld); g2.lda = Eld; g2.rows_per_batch = M;
+            g2.W = h->composed_w; g2.w_plane = pln(h, (int64_t)h->P1 * Eld); g2.ldw = Eld;
             g2.M = (int)M; g2.N = h->P1; g2.K = E;
             g2.scale = h->r_composed / sqrtf((float)E);
             g2.out_f32 = (float*)logits + h->col[st.classes[0]]; g2.ldo = h->ld_logits;

@@ -320,7 +320,9 @@ __global__ __launch_bounds__(WAVES * 64, AMX_ATTN_OCC) void attn_kernel(const At
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
     if (query < (packed ? klen : p.T)) {
-        T* dst = (T*)p.out + ((packed ? (int64_t)roff : (int64_t)n * p.T) + query) * (p.H * DH) + h * DH;
+        // (the output feeds the out-projection GEMM: interleaved planes in the two-plane modes, amx_common.h pidx())
+        const bool o_il = plane_is_il<NT>(p.out_plane);
+        T* dst = (T*)p.out + pidx(((packed ? (int64_t)roff : (int64_t)n * p.T) + query) * (p.H * DH) + h * DH, o_il);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(WAVES * 64, AMX_ATTN_OCC) void attn_kernel(const At
                     hv[j] = hi;
                     lv[j] = lo;
                 }
-                const int d0 = dt * 32 + 8 * g + 4 * hh;
+                const int d0 = (dt * 32 << (o_il ? 1 : 0)) + 8 * g + 4 * hh;
                 *(V4*)(dst + d0) = hv;
                 if (NT > 1) *(V4*)(dst + p.out_plane + d0) = lv;
             }

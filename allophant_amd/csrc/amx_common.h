@@ -23,6 +23,17 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 enum Precision { PREC_BF16 = 0, PREC_F16 = 1, PREC_BF16X3 = 2, PREC_F16X3 = 3 };
 inline int prec_planes(int p) { return p >= 2 ? 2 : 1; }
 
+// Interleaved planes (the layout of every GEMM operand in the two-plane modes, except the positional-convolution image):
+// the hi and lo values of 32 consecutive K elements share one 128-byte line, [hi x 32 | lo x 32], so that the operand DMA of
+// the ping-pong GEMM fetches whole lines (tools/dma_row_probe.hip: 128-byte row segments move 1.4x faster through L2 -> LDS
+// than the 64-byte segments of separate planes).  An operand is described as before by (pointer, plane distance, row stride)
+// in LOGICAL elements; plane == PLANE_IL says that it is interleaved: logical element offset o (row * ld + column, ld % 32
+// == 0) then lives at pidx(o) and its lo value PLANE_IL elements behind -- "lo = hi + plane" holds in both layouts.
+constexpr int64_t PLANE_IL = 32;
+__host__ __device__ __forceinline__ int64_t pidx(int64_t o, bool il) { return il ? (((o >> 5) << 6) | (o & 31)) : o; }
+template <int NT>
+__host__ __device__ __forceinline__ bool plane_is_il(int64_t plane) { return NT > 1 && plane == PLANE_IL; }
+
 template <typename T> struct Vec8;
 template <> struct Vec8<f16> { typedef f16x8 type; };
 template <> struct Vec8<bf16> { typedef bf16x8 type; };
@@ -161,8 +172,9 @@ constexpr int GEMM_LN_TILE_ROWS = 128;  // tile height of the row-complete conv 
 struct GemmParams {
     // A operand: row r lives at A + (r / rows_per_batch) * a_batch_stride + (r % rows_per_batch) * lda  (elements).
     // Overlapping rows (lda < K) express the strided 1-D convolutions as implicit GEMMs over channels-last input.
+    // Strides and offsets of A, W and out_p are LOGICAL elements in both plane layouts (plane == PLANE_IL: see pidx()).
     const void* A;
-    int64_t a_plane;  // distance hi plane -> lo plane (elements)
+    int64_t a_plane;  // distance hi plane -> lo plane (elements); PLANE_IL: interleaved
     int64_t lda;
     int64_t rows_per_batch;
     int64_t a_batch_stride;

@@ -51,8 +51,10 @@ bool ln_eligible(int NT, const GemmParams& p) {
     if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return false;
     if (p.M > p.rows_per_batch && (p.rows_per_batch < 256 || p.a_batch_stride < (p.rows_per_batch - 1) * p.lda)) return false;
     {
-        const int64_t a_span = (NT > 1 ? p.a_plane : 0) + (p.M > p.rows_per_batch ? p.a_batch_stride : 0) + 256 * p.lda + p.K;
-        const int64_t w_span = (NT > 1 ? p.w_plane : 0) + 512 * p.ldw + p.K;
+        const bool a_il = NT > 1 && p.a_plane == PLANE_IL, w_il = NT > 1 && p.w_plane == PLANE_IL;
+        if ((a_il && (p.lda % 32 || p.a_batch_stride % 32)) || (w_il && p.ldw % 32)) return false;
+        const int64_t a_span = (a_il ? 2 : 1) * ((p.M > p.rows_per_batch ? p.a_batch_stride : 0) + 256 * p.lda + p.K) + (NT > 1 ? p.a_plane : 0);
+        const int64_t w_span = (w_il ? 2 : 1) * (512 * p.ldw + p.K) + (NT > 1 ? p.w_plane : 0);
         if (a_span < 0 || w_span < 0 || a_span * 2 >= (int64_t)0xFFFFFF00 || w_span * 2 >= (int64_t)0xFFFFFF00) return false;
     }
     if (p.bias && ((uintptr_t)p.bias & 15)) return false;
@@ -81,12 +83,15 @@ bool pp_eligible(int NT, const GemmParams& p) {
     if (g_force_generic_gemm) return false;
     if (p.K % (128 / NT) != 0 || p.N < 256 || p.N % 4 != 0 || p.M < PP_MIN_ROWS) return false;
     if (p.lda % 8 || p.ldw % 8 || p.a_plane % 8 || p.w_plane % 8 || p.a_batch_stride % 8) return false;
+    // two planes: the slice-per-phase loop reads interleaved operands only (block-aligned rows)
+    if (NT > 1 && (p.a_plane != PLANE_IL || p.w_plane != PLANE_IL || p.lda % 32 || p.ldw % 32 || p.a_batch_stride % 32)) return false;
     if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return false;
     // DMA addressing: 32-bit byte offsets from the tile's first row; rows of a tile ascend in memory
     if (p.M > p.rows_per_batch && (p.rows_per_batch < 256 || p.a_batch_stride < (p.rows_per_batch - 1) * p.lda)) return false;
     {
-        const int64_t a_span = (NT > 1 ? p.a_plane : 0) + (p.M > p.rows_per_batch ? p.a_batch_stride : 0) + 256 * p.lda + p.K;
-        const int64_t w_span = (NT > 1 ? p.w_plane : 0) + 256 * p.ldw + p.K;
+        // (interleaved planes: every logical offset doubles and the lo value is 64 bytes behind)
+        const int64_t a_span = NT * ((p.M > p.rows_per_batch ? p.a_batch_stride : 0) + 256 * p.lda + p.K) + 64;
+        const int64_t w_span = NT * (256 * p.ldw + p.K) + 64;
         if (a_span < 0 || w_span < 0 || a_span * 2 >= (int64_t)0xFFFFFF00 || w_span * 2 >= (int64_t)0xFFFFFF00) return false;
     }
     if (p.bias && ((uintptr_t)p.bias & 15)) return false;
@@ -150,17 +155,18 @@ void launch_fixup(const GemmParams& p, int splits, hipStream_t stream) {
 template <typename T, int NT, int MI>
 void launch_pp_tiles(const GemmParams& p, int splits, hipStream_t stream) {
     static OncePerDevice attr;
+    constexpr int lds = pp::lds_bytes(NT, MI);
     if (attr.first())
-        (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<T, NT, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, pp::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<T, NT, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const int tiles = ((p.N + pp::BN - 1) / pp::BN) * ((p.M + MI * 32 - 1) / (MI * 32));
     const int cus = device_cus();
     const int units = tiles * splits;
-    dim3 grid(units < cus ? units : cus, 1, 1);  // persistent: one 128-KiB-LDS workgroup per CU
+    dim3 grid(units < cus ? units : cus, 1, 1);  // persistent: one 128-160-KiB-LDS workgroup per CU
     if (splits > 1) {
-        hipLaunchKernelGGL((gemm_pp_kernel<T, NT, MI>), grid, dim3(512), pp::LDS_BYTES, stream, split_view(p, splits));
+        hipLaunchKernelGGL((gemm_pp_kernel<T, NT, MI>), grid, dim3(512), lds, stream, split_view(p, splits));
         if (!p.defer_fixup) launch_fixup<T, NT>(p, splits, stream);
     } else {
-        hipLaunchKernelGGL((gemm_pp_kernel<T, NT, MI>), grid, dim3(512), pp::LDS_BYTES, stream, p);
+        hipLaunchKernelGGL((gemm_pp_kernel<T, NT, MI>), grid, dim3(512), lds, stream, p);
     }
 }
 
@@ -214,8 +220,10 @@ bool dma_tile_eligible(int NT, const GemmParams& p) {
     // rows of a tile ascend in memory and stay inside 32-bit byte offsets from the tile's first row
     if (p.M > p.rows_per_batch && p.a_batch_stride < (p.rows_per_batch - 1) * p.lda) return false;
     const int64_t batches_per_tile = p.M > p.rows_per_batch ? (128 + p.rows_per_batch - 1) / p.rows_per_batch + 1 : 0;
-    const int64_t a_span = (NT > 1 ? p.a_plane : 0) + batches_per_tile * p.a_batch_stride + 128 * p.lda + p.K;
-    const int64_t w_span = (NT > 1 ? p.w_plane : 0) + 64 * p.ldw + p.K;
+    const bool a_il = NT > 1 && p.a_plane == PLANE_IL, w_il = NT > 1 && p.w_plane == PLANE_IL;
+    if ((a_il && (p.lda % 32 || p.a_batch_stride % 32 || p.za % 32)) || (w_il && (p.ldw % 32 || p.zw % 32))) return false;
+    const int64_t a_span = (a_il ? 2 : 1) * (batches_per_tile * p.a_batch_stride + 128 * p.lda + p.K) + (NT > 1 ? p.a_plane : 0);
+    const int64_t w_span = (w_il ? 2 : 1) * (64 * p.ldw + p.K) + (NT > 1 ? p.w_plane : 0);
     if (a_span < 0 || w_span < 0 || a_span * 2 >= (int64_t)0xFFFFFF00 || w_span * 2 >= (int64_t)0xFFFFFF00) return false;
     return true;
 }

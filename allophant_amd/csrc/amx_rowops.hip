@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ au
                     }
                 }
                 if (active && t < T1) {
-                    T* dst = out + ((int64_t)n * T1 + t) * C + c0;
+                    T* dst = out + pidx(((int64_t)n * T1 + t) * C + c0, plane_is_il<NT>(out_plane));
                     if constexpr (CPL == 8) {
                         union { V2 h[4]; typename Vec8<T>::type v; } hv, lv;
 #pragma unroll
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ au
                 split16<T, NT>(y, hi[i], lo[i]);
             }
             if (active && t < T1) {
-                T* dst = out + ((int64_t)n * T1 + t) * C + c0;
+                T* dst = out + pidx(((int64_t)n * T1 + t) * C + c0, plane_is_il<NT>(out_plane));
 #pragma unroll
                 for (int i = 0; i < CPL; ++i)
                     if (c0 + i < C) {
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
                 split16<T, NT>(v[i].y, hi[1], lo[1]);
                 split16<T, NT>(v[i].z, hi[2], lo[2]);
                 split16<T, NT>(v[i].w, hi[3], lo[3]);
-                T* dst = out_p + row * ldp + c;
+                T* dst = out_p + pidx(row * ldp + c, plane_is_il<NT>(out_plane));
                 typedef typename Vec4<T>::type V4;
                 V4 hv = {hi[0], hi[1], hi[2], hi[3]};
                 *(V4*)dst = hv;
@@ -404,7 +404,8 @@ __global__ __launch_bounds__(256) void concat_kernel(const ConcatPart* __restric
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
-    T* dst = out + row * ldp;
+    const bool il = plane_is_il<NT>(out_plane);
+    const int64_t row0 = row * ldp;  // logical offset of the row; element c lives at pidx(row0 + c)
     int kend = 0;
     for (int pi = 0; pi < n_parts; ++pi) {
         const ConcatPart pt = parts[pi];
@@ -413,8 +414,9 @@ __global__ __launch_bounds__(256) void concat_kernel(const ConcatPart* __restric
             for (int c = lane; c < pt.width; c += 64) {
                 T hi, lo;
                 split16<T, NT>(src[c], hi, lo);
-                dst[pt.dst_col + c] = hi;
-                if (NT > 1) dst[out_plane + pt.dst_col + c] = lo;
+                T* dst = out + pidx(row0 + pt.dst_col + c, il);
+                dst[0] = hi;
+                if (NT > 1) dst[out_plane] = lo;
             }
         } else {
             const float* src = logits + row * ld_logits + pt.src_col;
@@ -427,16 +429,18 @@ __global__ __launch_bounds__(256) void concat_kernel(const ConcatPart* __restric
             for (int c = lane; c < pt.width; c += 64) {
                 T hi, lo;
                 split16<T, NT>(expf(src[c] - m) / s, hi, lo);
-                dst[pt.dst_col + c] = hi;
-                if (NT > 1) dst[out_plane + pt.dst_col + c] = lo;
+                T* dst = out + pidx(row0 + pt.dst_col + c, il);
+                dst[0] = hi;
+                if (NT > 1) dst[out_plane] = lo;
             }
         }
         int e = pt.dst_col + pt.width;
         kend = e > kend ? e : kend;
     }
     for (int c = kend + lane; c < kpad; c += 64) {
-        dst[c] = (T)0.f;
-        if (NT > 1) dst[out_plane + c] = (T)0.f;
+        T* dst = out + pidx(row0 + c, il);
+        dst[0] = (T)0.f;
+        if (NT > 1) dst[out_plane] = (T)0.f;
     }
 }
 
@@ -465,7 +469,7 @@ __global__ __launch_bounds__(256) void time_ln_pe_kernel(const float* __restrict
     }
     const float rs = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
     const float t = (float)(row % T_frames);
-    T* dst = out + row * kpad;
+    const bool il = plane_is_il<NT>(out_plane);
     for (int c = lane; c < kpad; c += 64) {
         float y = 0.f;
         if (c < C) {
@@ -477,8 +481,9 @@ __global__ __launch_bounds__(256) void time_ln_pe_kernel(const float* __restrict
         }
         T hi, lo;
         split16<T, NT>(y, hi, lo);
-        dst[c] = hi;
-        if (NT > 1) dst[out_plane + c] = lo;
+        T* dst = out + pidx(row * kpad + c, il);
+        dst[0] = hi;
+        if (NT > 1) dst[out_plane] = lo;
     }
 }
 
@@ -531,14 +536,16 @@ __global__ __launch_bounds__(256) void time_attention_kernel(const float* __rest
         if (kg == 0 && d < dh) {
             T hi, lo;
             split16<T, NT>(o * inv, hi, lo);
-            out[orow + hd * dh + d] = hi;
-            if (NT > 1) out[out_plane + orow + hd * dh + d] = lo;
+            T* dst = out + pidx(orow + hd * dh + d, plane_is_il<NT>(out_plane));
+            dst[0] = hi;
+            if (NT > 1) dst[out_plane] = lo;
         }
     }
     if (hd == 0)
         for (int c = C + lane; c < kpad; c += 64) {
-            out[orow + c] = (T)0.f;
-            if (NT > 1) out[out_plane + orow + c] = (T)0.f;
+            T* dst = out + pidx(orow + c, plane_is_il<NT>(out_plane));
+            dst[0] = (T)0.f;
+            if (NT > 1) dst[out_plane] = (T)0.f;
         }
 }
 
@@ -718,8 +725,9 @@ __global__ void pack_matrix_kernel(const float* __restrict__ src, int rows, int 
         float v = c < cols ? src[r * srs + c * scs] * scale : 0.f;
         T hi, lo;
         split16<T, NT>(v, hi, lo);
-        dst[r * ldd + c] = hi;
-        if (NT > 1) dst[dst_plane + r * ldd + c] = lo;
+        T* d = dst + pidx((int64_t)r * ldd + c, plane_is_il<NT>(dst_plane));
+        d[0] = hi;
+        if (NT > 1) d[dst_plane] = lo;
     }
 }
 
@@ -735,8 +743,9 @@ __global__ void pack_conv_w_kernel(const float* __restrict__ src, int Co, int Ci
         int co = (int)(r / k);
         T hi, lo;
         split16<T, NT>(src[((int64_t)co * Ci + ci) * k + j] * scale, hi, lo);
-        dst[i] = hi;
-        if (NT > 1) dst[dst_plane + i] = lo;
+        T* d = dst + pidx(i, plane_is_il<NT>(dst_plane));  // rows of Ci * k elements
+        d[0] = hi;
+        if (NT > 1) d[dst_plane] = lo;
     }
 }
 
@@ -790,8 +799,9 @@ __global__ void compose_kernel(const float* __restrict__ emb, int E, const int64
         composed[i] = s;
         T hi, lo;
         split16<T, NT>(s * scale, hi, lo);
-        dst[(int64_t)p * ldd + e] = hi;
-        if (NT > 1) dst[dst_plane + (int64_t)p * ldd + e] = lo;
+        T* d = dst + pidx((int64_t)p * ldd + e, plane_is_il<NT>(dst_plane));
+        d[0] = hi;
+        if (NT > 1) d[dst_plane] = lo;
     }
 }
 

@@ -38,6 +38,26 @@ static void fill16(void* d, size_t n, int seed, int prec, bool lo_plane) {
     }
     CK(hipMemcpy(d, h.data(), n * 2, hipMemcpyHostToDevice));
 }
+// the operand of a product: one plane, or (two-plane modes) the INTERLEAVED layout the kernels read (amx_common.h pidx():
+// [hi x 32 | lo x 32] per 32 K elements); n = logical elements, a multiple of 32 in the two-plane modes
+static void fill_operand(void* d, size_t n, int seed_hi, int seed_lo, int prec) {
+    if (prec_planes(prec) == 1) { fill16(d, n, seed_hi, prec, false); return; }
+    std::vector<unsigned short> hi(n), lo(n), out(2 * n);
+    {
+        void* tmp; CK(hipMalloc(&tmp, n * 2));
+        fill16(tmp, n, seed_hi, prec, false); CK(hipMemcpy(hi.data(), tmp, n * 2, hipMemcpyDeviceToHost));
+        fill16(tmp, n, seed_lo, prec, true); CK(hipMemcpy(lo.data(), tmp, n * 2, hipMemcpyDeviceToHost));
+        CK(hipFree(tmp));
+    }
+    for (size_t i = 0; i < n; ++i) {
+        const size_t ph = (size_t)pidx((int64_t)i, true);
+        out[ph] = hi[i];
+        out[ph + PLANE_IL] = lo[i];
+    }
+    CK(hipMemcpy(d, out.data(), 2 * n * 2, hipMemcpyHostToDevice));
+}
+static int64_t plane_of(int prec, size_t separate) { return prec_planes(prec) > 1 ? PLANE_IL : (int64_t)separate; }
+
 static void fill32(float* d, size_t n, int seed, float scale) {
     std::vector<float> h(n);
     srand(seed);
@@ -52,9 +72,11 @@ __global__ void ref_kernel(const T* A, int64_t a_plane, const T* W, int64_t w_pl
     int n = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
     if (n >= N || m >= M) return;
     double acc = 0;
+    const bool il = NT > 1;  // two planes: interleaved
     for (int k = 0; k < K; ++k) {
-        double a = (double)(float)A[(int64_t)m * K + k], w = (double)(float)W[(int64_t)n * K + k];
-        if (NT > 1) { a += (double)(float)A[a_plane + (int64_t)m * K + k]; w += (double)(float)W[w_plane + (int64_t)n * K + k]; }
+        const int64_t ia = pidx((int64_t)m * K + k, il), iw = pidx((int64_t)n * K + k, il);
+        double a = (double)(float)A[ia], w = (double)(float)W[iw];
+        if (NT > 1) { a += (double)(float)A[a_plane + ia]; w += (double)(float)W[w_plane + iw]; }
         acc += a * w;
     }
     out[(int64_t)m * N + n] = acc * scale + bias[n] + (res ? (double)res[(int64_t)m * N + n] : 0.0);
@@ -80,14 +102,13 @@ static double run_case(int prec, const Case& c, bool timing_only, double* us_pp,
     const int64_t rows_per_batch = c.conv_rows_per_batch ? c.conv_rows_per_batch : c.M;
     const int64_t lda = c.conv_lda ? c.conv_lda : c.K;
     const int64_t nbatch = (c.M + rows_per_batch - 1) / rows_per_batch;
-    const int64_t a_batch_stride = c.conv_rows_per_batch ? ((rows_per_batch - 1) * lda + c.K + 8 * 5) : 0;
+    const int64_t a_batch_stride = c.conv_rows_per_batch ? ((rows_per_batch - 1) * lda + c.K + 32 * 3) : 0;
     const size_t a_el = c.conv_rows_per_batch ? (size_t)(nbatch * a_batch_stride) : (size_t)c.M * c.K;
     const size_t w_el = (size_t)c.N * c.K;
     const size_t o_el = (size_t)c.M * c.N;
     void *A, *W;
     CK(hipMalloc(&A, a_el * 2 * NT)); CK(hipMalloc(&W, w_el * 2 * NT));
-    fill16(A, a_el, 1, prec, false); fill16(W, w_el, 2, prec, false);
-    if (NT > 1) { fill16((char*)A + a_el * 2, a_el, 3, prec, true); fill16((char*)W + w_el * 2, w_el, 4, prec, true); }
+    fill_operand(A, a_el, 1, 3, prec); fill_operand(W, w_el, 2, 4, prec);
     float *bias, *res; int* row_len;
     CK(hipMalloc(&bias, c.N * 4)); CK(hipMalloc(&res, o_el * 4));
     fill32(bias, c.N, 5, 0.5f); fill32(res, o_el, 6, 1.0f);
@@ -109,13 +130,13 @@ static double run_case(int prec, const Case& c, bool timing_only, double* us_pp,
             CK(hipMemset(q, 0, qk_el * 2 * NT)); CK(hipMemset(k, 0, qk_el * 2 * NT)); CK(hipMemset(vt, 0, qk_el * 2 * NT));
         }
         GemmParams g{};
-        g.A = A; g.a_plane = a_el; g.lda = lda; g.rows_per_batch = rows_per_batch; g.a_batch_stride = a_batch_stride;
-        g.W = W; g.w_plane = w_el; g.ldw = c.K; g.M = c.M; g.N = c.N; g.K = c.K;
+        g.A = A; g.a_plane = plane_of(prec, a_el); g.lda = lda; g.rows_per_batch = rows_per_batch; g.a_batch_stride = a_batch_stride;
+        g.W = W; g.w_plane = plane_of(prec, w_el); g.ldw = c.K; g.M = c.M; g.N = c.N; g.K = c.K;
         g.scale = c.scale; g.bias = bias; g.act = c.act;
         if (c.residual) { g.residual = res; g.ldr = c.N; }
         if (c.mask) { g.row_len = row_len; g.rows_T = T; }
         if (c.f32_out) { g.out_f32 = outf; g.ldo = c.N; }
-        if (c.planes_out) { g.out_p = outp; g.out_plane = o_el; g.ldp = c.N; }
+        if (c.planes_out) { g.out_p = outp; g.out_plane = plane_of(prec, o_el); g.ldp = c.N; }
         if (c.qkv) {
             g.mode = 1; g.q = q; g.k = k; g.v = vt; g.qk_plane = qk_el; g.T = T; g.Tp = Tp; g.H = H; g.dh = dh;
             g.row_len = row_len;
@@ -162,9 +183,12 @@ static double run_case(int prec, const Case& c, bool timing_only, double* us_pp,
             } else {
                 const unsigned short* a = (const unsigned short*)x.data(); const unsigned short* b = (const unsigned short*)y.data();
                 size_t n = x.size() / 2 / NT;
+                // the output planes of a product are interleaved like its operands; Q / K / V (r >= 2) are separate planes
+                const bool il = NT > 1 && r == 1;
                 for (size_t i = 0; i < n; ++i) {
-                    double va = to_f32(prec, a[i]), vb = to_f32(prec, b[i]);
-                    if (NT > 1) { va += to_f32(prec, a[n + i]); vb += to_f32(prec, b[n + i]); }
+                    const size_t ph = (size_t)pidx((int64_t)i, il), pl = il ? ph + PLANE_IL : n + i;
+                    double va = to_f32(prec, a[ph]), vb = to_f32(prec, b[ph]);
+                    if (NT > 1) { va += to_f32(prec, a[pl]); vb += to_f32(prec, b[pl]); }
                     double e = fabs(va - vb) / (1.0 + fabs(vb));
                     if (!(e <= worst)) worst = (e == e) ? e : 1e30;
                 }
@@ -175,8 +199,8 @@ static double run_case(int prec, const Case& c, bool timing_only, double* us_pp,
         double* truth; CK(hipMalloc(&truth, o_el * 8));
         dim3 grid((c.N + 127) / 128, c.M);
         const bool is_f16 = prec == PREC_F16 || prec == PREC_F16X3;
-        if (is_f16) hipLaunchKernelGGL(ref_kernel<amx::f16>, grid, dim3(128), 0, 0, (const amx::f16*)A, (int64_t)a_el, (const amx::f16*)W, (int64_t)w_el, NT, c.M, c.N, c.K, c.scale, bias, c.residual ? res : nullptr, truth);
-        else hipLaunchKernelGGL(ref_kernel<amx::bf16>, grid, dim3(128), 0, 0, (const amx::bf16*)A, (int64_t)a_el, (const amx::bf16*)W, (int64_t)w_el, NT, c.M, c.N, c.K, c.scale, bias, c.residual ? res : nullptr, truth);
+        if (is_f16) hipLaunchKernelGGL(ref_kernel<amx::f16>, grid, dim3(128), 0, 0, (const amx::f16*)A, plane_of(prec, a_el), (const amx::f16*)W, plane_of(prec, w_el), NT, c.M, c.N, c.K, c.scale, bias, c.residual ? res : nullptr, truth);
+        else hipLaunchKernelGGL(ref_kernel<amx::bf16>, grid, dim3(128), 0, 0, (const amx::bf16*)A, plane_of(prec, a_el), (const amx::bf16*)W, plane_of(prec, w_el), NT, c.M, c.N, c.K, c.scale, bias, c.residual ? res : nullptr, truth);
         std::vector<double> t(o_el); CK(hipMemcpy(t.data(), truth, o_el * 8, hipMemcpyDeviceToHost));
         double e[2] = {0, 0};
         for (int v = 0; v < 2; ++v) {
@@ -197,19 +221,19 @@ static void run_stamp(int prec, int M, int N, int K, const char* name) {
     size_t a_el = (size_t)M * K, w_el = (size_t)N * K, o_el = (size_t)M * N;
     void *A, *W; float *bias, *outf;
     CK(hipMalloc(&A, a_el * 2 * NT)); CK(hipMalloc(&W, w_el * 2 * NT)); CK(hipMalloc(&bias, N * 4)); CK(hipMalloc(&outf, o_el * 4));
-    fill16(A, a_el, 1, prec, false); fill16(W, w_el, 2, prec, false);
-    if (NT > 1) { fill16((char*)A + a_el * 2, a_el, 3, prec, true); fill16((char*)W + w_el * 2, w_el, 4, prec, true); }
+    fill_operand(A, a_el, 1, 3, prec); fill_operand(W, w_el, 2, 4, prec);
     fill32(bias, N, 5, 0.5f);
     const int nblk = 256;  // persistent grid: at most one workgroup per CU
     unsigned long long* st; CK(hipMalloc(&st, (size_t)nblk * 20 * 8)); CK(hipMemset(st, 0, (size_t)nblk * 20 * 8));
     GemmParams g{};
-    g.A = A; g.a_plane = a_el; g.lda = K; g.rows_per_batch = M; g.W = W; g.w_plane = w_el; g.ldw = K; g.M = M; g.N = N; g.K = K;
+    g.A = A; g.a_plane = plane_of(prec, a_el); g.lda = K; g.rows_per_batch = M; g.W = W; g.w_plane = plane_of(prec, w_el); g.ldw = K;
+    g.M = M; g.N = N; g.K = K;
     g.scale = 1.f; g.bias = bias; g.out_f32 = outf; g.ldo = N; g.stamps = st;
     for (int i = 0; i < 30; ++i) launch_gemm(prec, g, 0);  // warm: let the clock settle under load
     CK(hipDeviceSynchronize());
     std::vector<unsigned long long> h((size_t)nblk * 20);
     CK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
-    const int nseg = (NT == 1 ? 1 : 3) * (K / 32);
+    const int nseg = K / 32;  // LOAD + MFMA segment pairs per tile: one per 32-deep K slice in either mode
     for (int grp = 0; grp < 2; ++grp) {
         double s[9] = {0}; int cnt = 0; double tiles = 0;
         for (int b = 0; b < nblk; ++b) {
@@ -252,12 +276,12 @@ int main(int argc, char** argv) {
         size_t a_el = (size_t)M * K, w_el = (size_t)N * K, o_el = (size_t)M * N;
         void *A, *W, *outp; float* bias;
         CK(hipMalloc(&A, a_el * 2 * NT)); CK(hipMalloc(&W, w_el * 2 * NT)); CK(hipMalloc(&bias, N * 4)); CK(hipMalloc(&outp, o_el * 2 * NT));
-        fill16(A, a_el, 1, prec, false); fill16(W, w_el, 2, prec, false);
-        if (NT > 1) { fill16((char*)A + a_el * 2, a_el, 3, prec, true); fill16((char*)W + w_el * 2, w_el, 4, prec, true); }
+        fill_operand(A, a_el, 1, 3, prec); fill_operand(W, w_el, 2, 4, prec);
         fill32(bias, N, 5, 0.5f);
         GemmParams g{};
-        g.A = A; g.a_plane = a_el; g.lda = K; g.rows_per_batch = M; g.W = W; g.w_plane = w_el; g.ldw = K; g.M = M; g.N = N; g.K = K;
-        g.scale = 1.f; g.bias = bias; g.act = 1; g.out_p = outp; g.out_plane = o_el; g.ldp = N;
+        g.A = A; g.a_plane = plane_of(prec, a_el); g.lda = K; g.rows_per_batch = M; g.W = W; g.w_plane = plane_of(prec, w_el); g.ldw = K;
+        g.M = M; g.N = N; g.K = K;
+        g.scale = 1.f; g.bias = bias; g.act = 1; g.out_p = outp; g.out_plane = plane_of(prec, o_el); g.ldp = N;
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         double total_ms = 0;
         while (total_ms < seconds * 1e3) {
