@@ -251,11 +251,21 @@ int dma_tile_shape(int NT, const GemmParams& p, int zdim) {
 template <typename T, int NT, int BM, int BN, int WM, int WN, int STAGES>
 void launch_gemm_dma(const GemmParams& q, int zdim, hipStream_t stream) {
     constexpr int lds = STAGES * NT * (BM + BN) * 128;
+    dim3 grid((q.N + BN - 1) / BN, (q.M + BM - 1) / BM, zdim);
+    if constexpr (NT == 2) {
+        if (q.a_plane == PLANE_IL && q.w_plane == PLANE_IL) {  // interleaved operands: whole-line pieces
+            static OncePerDevice attr_il;
+            if (attr_il.first())
+                (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<T, NT, BM, BN, WM, WN, STAGES, true>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipLaunchKernelGGL((gemm_dma_kernel<T, NT, BM, BN, WM, WN, STAGES, true>), grid, dim3(256), lds, stream, q);
+            return;
+        }
+    }
     static OncePerDevice attr;
     if (attr.first())
         (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<T, NT, BM, BN, WM, WN, STAGES>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    dim3 grid((q.N + BN - 1) / BN, (q.M + BM - 1) / BM, zdim);
     hipLaunchKernelGGL((gemm_dma_kernel<T, NT, BM, BN, WM, WN, STAGES>), grid, dim3(256), lds, stream, q);
 }
 
