@@ -46,7 +46,7 @@ MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/f16 MFMA peak, /opt/skills/guides/MI355X
 HBM_PEAK_GBS = 8000.0
 MEASURED_MFMA_CEILING_TFLOPS = 2100.0  # 16x16x32 f16, two waves per SIMD (profiles/r02_mfma_only_ceiling.log)
 CONV0_PATTERN_STORE_GBS = 5660.0  # conv0's own store pattern without its arithmetic (tools/store_bw_probe.hip, profiles/r03_store_bw.log)
-TRAFFIC_FILES = ("r03_traffic.json", "r02_traffic.json")  # newest first; written by tools/collect_profiles.py
+TRAFFIC_FILES = ("r03il_traffic.json", "r03_traffic.json", "r02_traffic.json")  # newest first; written by tools/collect_profiles.py
 
 
 def build_spec():
@@ -425,7 +425,7 @@ def main():
                     "frac_of_own_probe": conv0_gbs / CONV0_PATTERN_STORE_GBS if conv0_gbs else None,
                 },
                 "conv1_5": {
-                    "kernel": "gemm_ln_kernel<T16, planes>: 128x512 row-complete implicit GEMM + LayerNorm + GELU",
+                    "kernel": "gemm_ln_il_kernel<T16> (two planes; gemm_ln_kernel<T16, 1> with one): 128x512 row-complete implicit GEMM + LayerNorm + GELU",
                     "bound": "mfma", "flops": w["gemm_ln"], "algorithmic_bytes": w["gemm_ln_bytes"], "ms": ln_ms,
                     "achieved": ln_tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": ln_tf / MFMA_PEAK_TFLOPS if ln_tf else None,

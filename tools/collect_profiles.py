@@ -78,7 +78,7 @@ for arg in sys.argv[2:]:
         traffic[precision]["conv0_hbm_bytes_per_launch"] = (2.0 * f + w) * 1024.0
         traffic[precision]["conv0_fetch_size_kb_raw"] = f
         traffic[precision]["conv0_write_size_kb"] = w
-    ln = [v for k, v in merged.items() if "gemm_ln_kernel" in k]
+    ln = [v for k, v in merged.items() if "gemm_ln_kernel" in k or "gemm_ln_il_kernel" in k]
     if ln:
         f = sum(v["FETCH_SIZE"]["sum"] for v in ln)
         w = sum(v["WRITE_SIZE"]["sum"] for v in ln)
