@@ -487,6 +487,36 @@ def test_random_models_and_geometries_against_oracle(amd, seed):
     est.close()
 
 
+@pytest.mark.parametrize("conv_dim,ffn", [(48, 256), (32, 136), (24, 72)])
+@pytest.mark.parametrize("precision", ["f16x3", "bf16x3"])
+def test_shapes_outside_the_interleaved_layout_against_oracle(amd, conv_dim, ffn, precision):
+    """The two-plane modes store GEMM operands as interleaved planes when conv_dim and ffn are multiples of 32 (every
+    wav2vec 2.0 shape); other shapes keep separate hi / lo planes and run on the generic tile kernels.  Same gate."""
+    from oracle import allophant_oracle as O
+
+    enc = S.tiny_encoder(2)
+    enc["conv_dim"], enc["ffn"] = conv_dim, ffn
+    spec = S.multitask_spec(enc, ["syllabic", "long", "nasal"], embedding_size=24, train_phonemes=9, n_features=4)
+    phoneme = {c["name"]: c for c in spec["classes"]}[S.PHONEME]
+    phoneme["dependencies"] = [S.OUTPUT, "long", "nasal"]  # a concatenated classifier input (padded K)
+    S.validate(spec)
+    state = synthetic.make_state_dict(spec, seed=11)
+    est = amd.Estimator(spec, state, "cuda:0", precision)
+    tfi = synthetic.make_inventory(spec, 7, seed=3)
+    offsets = synthetic.category_offsets(spec)
+    for n, length in ((3, 9000), (1, 33000), (12, 16000)):  # the last one: enough rows for the persistent kernels
+        audio, lengths = synthetic.make_audio(n, length, seed=n, ragged=True)
+        lengths = torch.clamp(lengths, min=400)
+        for i in range(n):
+            audio[i, int(lengths[i]):] = 0
+        pred = est.predict(amd.Batch(audio.cuda(), lengths, torch.zeros(n, dtype=torch.long)), tfi)
+        ref, ref_len = O.predict(audio, lengths, state, spec, tfi, offsets)
+        assert torch.equal(pred.lengths.cpu(), ref_len)
+        for k in ref:
+            assert max_abs_valid_tm(pred.outputs[k].cpu(), ref[k], ref_len) < GATE, (conv_dim, ffn, n, k)
+    est.close()
+
+
 @pytest.mark.parametrize("precision", ["f16x3", "bf16x3"])
 def test_long_utterances(amd, precision):
     """A 25 s utterance (20 key tiles per query block) next to 9 s and 1.3 s ones against the oracle, with the encoder
