@@ -72,14 +72,15 @@ void launch_gemm_ln(const GemmParams& p, hipStream_t stream) {
     if (tiles <= 0) return;
     const int cus = device_cus();
     dim3 grid(tiles < cus ? tiles : cus, 1, 1);
-    if constexpr (NT == 2) {
-        // interleaved operands: whole-line operand DMA, one segment pair per K slice
+    {
+        // whole-line operand DMA, one segment pair per K slice (two planes: interleaved operands only)
         static const bool plain_loop = getenv("AMX_LN_SEGMENT_LOOP") && atoi(getenv("AMX_LN_SEGMENT_LOOP")) != 0;  // developer A/B
-        if (!plain_loop && p.a_plane == PLANE_IL && p.w_plane == PLANE_IL && p.out_plane == PLANE_IL && p.K % 64 == 0) {
+        const bool layout_ok = NT == 1 || (p.a_plane == PLANE_IL && p.w_plane == PLANE_IL && p.out_plane == PLANE_IL);
+        if (!plain_loop && layout_ok && p.K % (128 / NT) == 0) {
             static OncePerDevice attr_il;
             if (attr_il.first())
-                (void)hipFuncSetAttribute((const void*)gemm_ln_il_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, ppi::LDS_BYTES);
-            hipLaunchKernelGGL((gemm_ln_il_kernel<T>), grid, dim3(512), ppi::LDS_BYTES, stream, p);
+                (void)hipFuncSetAttribute((const void*)gemm_ln_il_kernel<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, ppi::LDS_BYTES);
+            hipLaunchKernelGGL((gemm_ln_il_kernel<T, NT>), grid, dim3(512), ppi::LDS_BYTES, stream, p);
             return;
         }
     }

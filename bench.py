@@ -425,7 +425,7 @@ def main():
                     "frac_of_own_probe": conv0_gbs / CONV0_PATTERN_STORE_GBS if conv0_gbs else None,
                 },
                 "conv1_5": {
-                    "kernel": "gemm_ln_il_kernel<T16> (two planes; gemm_ln_kernel<T16, 1> with one): 128x512 row-complete implicit GEMM + LayerNorm + GELU",
+                    "kernel": "gemm_ln_il_kernel<T16, planes>: 128x512 row-complete implicit GEMM + LayerNorm + GELU",
                     "bound": "mfma", "flops": w["gemm_ln"], "algorithmic_bytes": w["gemm_ln_bytes"], "ms": ln_ms,
                     "achieved": ln_tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": ln_tf / MFMA_PEAK_TFLOPS if ln_tf else None,
