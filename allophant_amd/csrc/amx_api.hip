@@ -1108,6 +1108,18 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         HIPCHK(h, hipMemsetAsync(kb, 0, qkv_bytes, s));
         HIPCHK(h, hipMemsetAsync(vtb, 0, qkv_bytes, s));
     }
+    // Packed from the feature projection on ("early"): the last conv layer's LayerNorm pass gathers the valid frames, so the
+    // feature projection, the positional convolution (window kernel: skips the frame blocks beyond an utterance), the final
+    // LayerNorm, the classifier heads and the log-softmax read packed rows too and nothing is packed or unpacked in between.
+    // Needs the window kernel (the grouped-GEMM form of the positional convolution addresses padded rows) and no time-layer
+    // head (its attention walks (utterance, frame) pairs); otherwise the rows are packed after the positional convolution
+    // and unpacked before the final LayerNorm, as in round 2.
+    static const bool no_window = getenv("AMX_NO_POSCONV_WINDOW") && atoi(getenv("AMX_NO_POSCONV_WINDOW")) != 0;  // developer A/B switch
+    static const bool late_pack = getenv("AMX_PACK_LATE") && atoi(getenv("AMX_PACK_LATE")) != 0;                  // developer A/B switch
+    const bool window_ok = !no_window && posconv_window_eligible(D, c.pos_groups, c.pos_kernel, N, T, Tpad, (int64_t)N * Tpad * D);
+    bool any_time_layer = false;
+    for (auto& st : h->steps) any_time_layer |= st.time_heads > 0;
+    const bool packed_early = packed && window_ok && !any_time_layer && !late_pack;
     void* hpk = nullptr;
     if (packed) {
         WS("h_packed", (size_t)Mp * D * 4, hpk);
@@ -1230,9 +1242,15 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             { Timed t_(h, AMX_KC_ROWNORM); launch_rownorm(prec, (const float*)preln, C, rows_out, C, h->conv_g[i], h->conv_be[i], 1, nullptr, nullptr, 1e-5f,
                            0.f, other, out_plane, C, nullptr, 0, s); }
         } else if (!keep) {
-            // last conv layer: LN + GELU, then the feature-projection LayerNorm in the same pass
-            { Timed t_(h, AMX_KC_CONV_TAIL); launch_rownorm(prec, (const float*)preln, C, rows_out, C, h->conv_g[i], h->conv_be[i], 1, h->fp_g, h->fp_b, 1e-5f,
-                           c.eps, other, out_plane, C, nullptr, 0, s); }
+            // last conv layer: LN + GELU, then the feature-projection LayerNorm in the same pass (packed_early: only the valid
+            // frames, written back to back)
+            Timed t_(h, AMX_KC_CONV_TAIL);
+            if (packed_early)
+                launch_rownorm_to_packed(prec, (const float*)preln, C, rows_out, C, h->conv_g[i], h->conv_be[i], 1, h->fp_g, h->fp_b, 1e-5f,
+                                         c.eps, other, out_plane, C, (const int*)d_rowoff, (const int*)d_frames, T, s);
+            else
+                launch_rownorm(prec, (const float*)preln, C, rows_out, C, h->conv_g[i], h->conv_be[i], 1, h->fp_g, h->fp_b, 1e-5f,
+                               c.eps, other, out_plane, C, nullptr, 0, s);
         } else {
             { Timed t_(h, AMX_KC_ROWNORM); launch_rownorm(prec, (const float*)preln, C, rows_out, C, h->conv_g[i], h->conv_be[i], 1, nullptr, nullptr, 1e-5f,
                            0.f, nullptr, 0, 0, conv_dbg, C, s); }
@@ -1245,24 +1263,28 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     // ---- feature projection (+ zero padded frames) ----
     {
         GemmParams g{};
-        g.A = cur; g.a_plane = cur_plane; g.lda = C; g.rows_per_batch = M; g.a_batch_stride = 0;
+        const int64_t Mfp = packed_early ? Mp : M;  // packed_early: the valid frames only, no row mask needed
+        g.A = cur; g.a_plane = cur_plane; g.lda = C; g.rows_per_batch = Mfp; g.a_batch_stride = 0;
         g.W = h->fp_w; g.w_plane = pln(h, (int64_t)D * C); g.ldw = C;
-        g.M = (int)M; g.N = D; g.K = C;
+        g.M = (int)Mfp; g.N = D; g.K = C;
         g.scale = h->fp_r; g.bias = h->fp_bias;
-        g.row_len = (const int*)d_frames; g.rows_T = T;
-        g.out_f32 = (float*)hbuf; g.ldo = D;
+        if (!packed_early) { g.row_len = (const int*)d_frames; g.rows_T = T; }
+        g.out_f32 = (float*)(packed_early ? hpk : hbuf); g.ldo = D;
         { Timed t_(h, gemm_class(prec, g)); run_gemm(prec, g, s); }
     }
     // ---- positional conv embedding: h += GELU(grouped conv(h)) ----
     {
-        { Timed t_(h, AMX_KC_OTHER); launch_posconv_pack(prec, (const float*)hbuf, N, T, D, c.pos_groups, c.pos_kernel / 2, Tpad, hg,
-                            (int64_t)N * Tpad * D, s); }
+        const int* pk_off = packed_early ? (const int*)d_rowoff : nullptr;
+        const int* pk_len = packed_early ? (const int*)d_frames : nullptr;
+        float* hcur = (float*)(packed_early ? hpk : hbuf);
+        { Timed t_(h, AMX_KC_OTHER); launch_posconv_pack(prec, hcur, N, T, D, c.pos_groups, c.pos_kernel / 2, Tpad, hg,
+                            (int64_t)N * Tpad * D, pk_off, pk_len, s); }
         // AMX_NO_POSCONV_WINDOW=1: developer A/B switch (grouped implicit GEMM on the tile kernels instead)
-        static const bool no_window = getenv("AMX_NO_POSCONV_WINDOW") && atoi(getenv("AMX_NO_POSCONV_WINDOW")) != 0;
-        if (!no_window && posconv_window_eligible(D, c.pos_groups, c.pos_kernel, N, T, Tpad, (int64_t)N * Tpad * D)) {
+        if (window_ok) {
             Timed t_(h, AMX_KC_GEMM_TILE);
             launch_posconv_window(prec, hg, (int64_t)N * Tpad * D, h->pos_w, (int64_t)D * cg * c.pos_kernel,
-                                  (int64_t)cg * c.pos_kernel, h->pos_b, h->pos_r, (float*)hbuf, N, T, Tpad, D, c.pos_groups, c.pos_kernel, s);
+                                  (int64_t)cg * c.pos_kernel, h->pos_b, h->pos_r, hcur, N, T, Tpad, D, c.pos_groups, c.pos_kernel,
+                                  pk_off, pk_len, s);
         } else {
         GemmParams g{};
         g.A = hg; g.a_plane = (int64_t)N * Tpad * D; g.lda = cg; g.rows_per_batch = T; g.a_batch_stride = (int64_t)Tpad * cg;
@@ -1279,7 +1301,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     void* const hpad = hbuf;     // the padded residual stream [N * T, D]
     const int64_t Mpad = M;
     if (packed) {
-        { Timed t_(h, AMX_KC_OTHER); launch_pack_rows((const float*)hpad, (float*)hpk, (const int*)d_rowoff, (const int*)d_frames, N, T, D, false, s); }
+        if (!packed_early) { Timed t_(h, AMX_KC_OTHER); launch_pack_rows((const float*)hpad, (float*)hpk, (const int*)d_rowoff, (const int*)d_frames, N, T, D, false, s); }
         hbuf = hpk;
     }
     const int64_t Mrows = packed ? Mp : Mpad;  // rows the layers work on
@@ -1318,8 +1340,13 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         if (saved[l]) {
             // a classifier reads hidden state l (OUTPUT_l, acoustic_model.py:478-483): padded layout; with packed rows the padded
             // frames take their pre-encoder rows (finite, as meaningless as any padded frame) and the valid ones are scattered in
-            HIPCHK(h, hipMemcpyAsync(saved[l], packed ? hpad : hbuf, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s));
-            if (packed) launch_pack_rows(saved[l], (float*)hbuf, (const int*)d_rowoff, (const int*)d_frames, N, T, D, true, s);
+            // (packed_early: the classifiers read packed rows, the copy is the packed stream as it is)
+            if (packed_early) {
+                HIPCHK(h, hipMemcpyAsync(saved[l], hbuf, (size_t)Mp * D * 4, hipMemcpyDeviceToDevice, s));
+            } else {
+                HIPCHK(h, hipMemcpyAsync(saved[l], packed ? hpad : hbuf, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s));
+                if (packed) launch_pack_rows(saved[l], (float*)hbuf, (const int*)d_rowoff, (const int*)d_frames, N, T, D, true, s);
+            }
         }
         {
             GemmParams g{};
@@ -1371,15 +1398,16 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             g.scale = ly.r_2; g.bias = ly.b2;
             g.residual = (const float*)hbuf; g.ldr = D; g.out_f32 = (float*)hbuf; g.ldo = D;
             // (the last layer of a packed batch is followed by the unpacking, not by a LayerNorm of these rows)
-            residual_gemm(g, !(packed && l == c.layers - 1));
+            residual_gemm(g, !(packed && !packed_early && l == c.layers - 1));
         }
     }
-    if (packed) {
+    if (packed && !packed_early) {
         // back to the padded layout for the final LayerNorm and the projection (padded frames keep their pre-encoder rows)
         { Timed t_(h, AMX_KC_OTHER); launch_pack_rows((const float*)hpad, (float*)hpk, (const int*)d_rowoff, (const int*)d_frames, N, T, D, true, s); }
         hbuf = hpad;
     }
-    stream_norm(h->fln_g, h->fln_b, M, pln(h, M * D), (float*)hfin);
+    const int64_t Mh = packed_early ? Mp : M;  // rows of the final LayerNorm and of the classifier heads
+    stream_norm(h->fln_g, h->fln_b, Mh, pln(h, Mh * D), (float*)hfin);
 
     // ---- hierarchical projection ----
     const int E = c.embedding_size;
@@ -1407,7 +1435,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     const bool blanks = c.dependency_blanks != 0;
     for (auto& st : h->steps) {
         const void* A = xp;
-        int64_t a_plane = pln(h, M * D), lda = D;
+        int64_t a_plane = pln(h, Mh * D), lda = D;
         if (!st.direct_output) {
             for (size_t i = 0; i < st.parts.size(); ++i) {
                 int dep = st.part_dep[i];
@@ -1430,46 +1458,46 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
                 HIPCHK(h, hipStreamSynchronize(s));
                 st.parts_uploaded = st.parts;
             }
-            { Timed t_(h, AMX_KC_OTHER); launch_concat(prec, st.parts_dev, (int)st.parts.size(), (const float*)logits, h->ld_logits, M, cat,
-                          pln(h, M * st.Kpad), st.Kpad, st.Kpad, s); }
-            A = cat; a_plane = pln(h, M * st.Kpad); lda = st.Kpad;
+            { Timed t_(h, AMX_KC_OTHER); launch_concat(prec, st.parts_dev, (int)st.parts.size(), (const float*)logits, h->ld_logits, Mh, cat,
+                          pln(h, Mh * st.Kpad), st.Kpad, st.Kpad, s); }
+            A = cat; a_plane = pln(h, Mh * st.Kpad); lda = st.Kpad;
         }
         GemmParams g{};
-        g.A = A; g.a_plane = a_plane; g.lda = lda; g.rows_per_batch = M;
+        g.A = A; g.a_plane = a_plane; g.lda = lda; g.rows_per_batch = Mh;
         g.W = st.W; g.w_plane = pln(h, (int64_t)st.rows * st.Kpad); g.ldw = st.Kpad;
-        g.M = (int)M; g.N = st.rows; g.K = st.Kpad;
+        g.M = (int)Mh; g.N = st.rows; g.K = st.Kpad;
         g.scale = st.r_w; g.bias = st.bias;
         if (st.time_heads > 0) {
             // ProjectingMultiheadAttention.forward (acoustic_model.py:255-268)
             const int Co = st.rows, Cp = st.Cpad;
             g.out_f32 = (float*)tl_x; g.ldo = Co;
             { Timed t_(h, gemm_class(prec, g)); run_gemm(prec, g, s); }
-            { Timed t_(h, AMX_KC_OTHER); launch_time_ln_pe(prec, (const float*)tl_x, M, Co, T, st.tl_g, st.tl_b, 1e-5f, st.tl_pe, tl_p,
-                              pln(h, M * Cp), Cp, s); }
+            { Timed t_(h, AMX_KC_OTHER); launch_time_ln_pe(prec, (const float*)tl_x, Mh, Co, T, st.tl_g, st.tl_b, 1e-5f, st.tl_pe, tl_p,
+                              pln(h, Mh * Cp), Cp, s); }
             GemmParams gi{};
-            gi.A = tl_p; gi.a_plane = pln(h, M * Cp); gi.lda = Cp; gi.rows_per_batch = M;
+            gi.A = tl_p; gi.a_plane = pln(h, Mh * Cp); gi.lda = Cp; gi.rows_per_batch = Mh;
             gi.W = st.tl_win; gi.w_plane = pln(h, (int64_t)3 * Co * Cp); gi.ldw = Cp;
-            gi.M = (int)M; gi.N = 3 * Co; gi.K = Cp;
+            gi.M = (int)Mh; gi.N = 3 * Co; gi.K = Cp;
             gi.scale = st.r_tin; gi.bias = st.tl_bin;
             gi.out_f32 = (float*)tl_qkv; gi.ldo = 3 * Co;
             { Timed t_(h, gemm_class(prec, gi)); run_gemm(prec, gi, s); }
             { Timed t_(h, AMX_KC_OTHER); launch_time_attention(prec, (const float*)tl_qkv, (const int*)d_frames, N, T, Co, st.time_heads,
-                                  tl_p, pln(h, M * Cp), Cp, s); }
+                                  tl_p, pln(h, Mh * Cp), Cp, s); }
             // out_proj lands where the plain linear classifier would have written
             g = GemmParams{};
-            g.A = tl_p; g.a_plane = pln(h, M * Cp); g.lda = Cp; g.rows_per_batch = M;
+            g.A = tl_p; g.a_plane = pln(h, Mh * Cp); g.lda = Cp; g.rows_per_batch = Mh;
             g.W = st.tl_wout; g.w_plane = pln(h, (int64_t)Co * Cp); g.ldw = Cp;
-            g.M = (int)M; g.N = Co; g.K = Cp;
+            g.M = (int)Mh; g.N = Co; g.K = Cp;
             g.scale = st.r_tout; g.bias = st.tl_bout;
         }
         if (st.composed) {
-            g.out_p = ebuf; g.out_plane = pln(h, M * Eld); g.ldp = Eld;
+            g.out_p = ebuf; g.out_plane = pln(h, Mh * Eld); g.ldp = Eld;
             { Timed t_(h, gemm_class(prec, g)); run_gemm(prec, g, s); }
             // logits = (e @ composed) / sqrt(E)   (acoustic_model.py:234)
             GemmParams g2{};
-            g2.A = ebuf; g2.a_plane = pln(h, M * Eld); g2.lda = Eld; g2.rows_per_batch = M;
+            g2.A = ebuf; g2.a_plane = pln(h, Mh * Eld); g2.lda = Eld; g2.rows_per_batch = Mh;
             g2.W = h->composed_w; g2.w_plane = pln(h, (int64_t)h->P1 * Eld); g2.ldw = Eld;
-            g2.M = (int)M; g2.N = h->P1; g2.K = E;
+            g2.M = (int)Mh; g2.N = h->P1; g2.K = E;
             g2.scale = h->r_composed / sqrtf((float)E);
             g2.out_f32 = (float*)logits + h->col[st.classes[0]]; g2.ldo = h->ld_logits;
             { Timed t_(h, gemm_class(prec, g2)); run_gemm(prec, g2, s); }
@@ -1479,7 +1507,8 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         }
     }
     { Timed t_(h, AMX_KC_OTHER); launch_logsoftmax_out(h->out_unique_dev, (int)h->out_unique.size(), (const float*)logits, h->ld_logits, N, T,
-                          (const int*)d_frames, (flags & AMX_FLAG_RAW_LOGITS) ? 0 : 1, d_out, h->nonfinite, s); }
+                          (const int*)d_frames, (flags & AMX_FLAG_RAW_LOGITS) ? 0 : 1, d_out, h->nonfinite,
+                          packed_early ? (const int*)d_rowoff : nullptr, s); }
     HIPCHK(h, hipGetLastError());
     if (flags & AMX_FLAG_HOST_IO) {
         HIPCHK(h, hipMemcpyAsync(out, d_out, (size_t)total * 4, hipMemcpyDeviceToHost, s));

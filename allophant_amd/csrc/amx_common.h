@@ -283,15 +283,23 @@ void launch_pack_rows(const float* padded, float* packed, const int* row_off, co
 void launch_rownorm(int prec, const float* x, int64_t ldx, int64_t M, int D, const float* gamma1, const float* beta1,
                     int gelu, const float* gamma2, const float* beta2, float eps1, float eps2, void* out_p,
                     int64_t out_plane, int64_t ldp, float* out_f32, int64_t ldo, hipStream_t s);
-// grouped, zero-padded 16-bit image of the (masked) projected features for the positional convolution
+// the same with the rows of a ragged batch gathered on the way out: input row n * T_rows + t -> plane row row_off[n] + t,
+// frames t >= frame_len[n] dropped (the feature projection of a ragged batch then runs on the valid frames only)
+void launch_rownorm_to_packed(int prec, const float* x, int64_t ldx, int64_t M, int D, const float* gamma1, const float* beta1,
+                              int gelu, const float* gamma2, const float* beta2, float eps1, float eps2, void* out_p,
+                              int64_t out_plane, int64_t ldp, const int* row_off, const int* frame_len, int T_rows, hipStream_t s);
+// grouped, zero-padded 16-bit image of the (masked) projected features for the positional convolution; row_off / frame_len
+// (may be null): h holds the packed rows of a ragged batch
 void launch_posconv_pack(int prec, const float* h, int N, int T, int D, int G, int pad_front, int Tpad, void* out,
-                         int64_t out_plane, hipStream_t s);
+                         int64_t out_plane, const int* row_off, const int* frame_len, hipStream_t s);
 
 // window-resident grouped positional convolution (amx_posconv.hip): h[n, t, g*64 + co] += gelu(bias + conv) from the padded
 // image [G][N][Tpad][64] and the weights [G][64][taps * 64]; eligible when hidden / groups == 64 and taps <= 128
 bool posconv_window_eligible(int D, int G, int taps, int N, int Tn, int Tpad, int64_t image_plane);
+// (row_off / frame_len, may be null: h holds the packed rows of a ragged batch; frame blocks beyond an utterance are skipped)
 void launch_posconv_window(int prec, const void* image, int64_t image_plane, const void* weights, int64_t w_plane, int64_t ldw,
-                           const float* bias, float scale, float* h, int N, int Tn, int Tpad, int D, int G, int taps, hipStream_t s);
+                           const float* bias, float scale, float* h, int N, int Tn, int Tpad, int D, int G, int taps, const int* row_off,
+                           const int* frame_len, hipStream_t s);
 
 struct ConcatPart {
     int type;     // 0: fp32 hidden rows -> planes; 1: softmax over logits columns
@@ -318,8 +326,9 @@ struct OutDesc {
                       // (geometry-independent, so the device table only changes with the inventory)
 };
 // `nonfinite` (device counter, may be null): incremented once per valid frame whose logits hold a NaN or an infinity
+// `row_off` (may be null): the logits rows are the packed rows of a ragged batch (utterance n at row_off[n])
 void launch_logsoftmax_out(const OutDesc* descs_dev, int n_out, const float* logits, int64_t ld, int N, int T,
-                           const int* frame_len, int log_probs, float* out, int* nonfinite, hipStream_t s);
+                           const int* frame_len, int log_probs, float* out, int* nonfinite, const int* row_off, hipStream_t s);
 void launch_greedy_ctc(const OutDesc* descs_dev, int n_out, const float* out, const int* frame_len, int N, int T,
                        int64_t* tokens, int64_t* timesteps, int* counts, float* scores, hipStream_t s);
 // the same decoder over one [N, T, C] emission tensor with element strides (stride_n, stride_t, 1)

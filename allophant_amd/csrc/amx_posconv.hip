@@ -34,7 +34,8 @@ template <typename T, int NT>
 __global__ __launch_bounds__(512, 2) void posconv_window_kernel(const T* __restrict__ image, int64_t image_plane,
                                                                 const T* __restrict__ weights, int64_t w_plane, int64_t ldw,
                                                                 const float* __restrict__ bias, float* __restrict__ h,
-                                                                int N, int Tn, int Tpad, int D, int taps, float scale) {
+                                                                int N, int Tn, int Tpad, int D, int taps, float scale,
+                                                                const int* __restrict__ row_off, const int* __restrict__ frame_len) {
     typedef typename Vec8<T>::type V8;
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -46,6 +47,11 @@ __global__ __launch_bounds__(512, 2) void posconv_window_kernel(const T* __restr
     const int tiles_per_utt = (Tn + PC_ROWS - 1) / PC_ROWS;
     const int n = blockIdx.x / tiles_per_utt, t0 = (blockIdx.x % tiles_per_utt) * PC_ROWS;
     const int g = blockIdx.y, G = gridDim.y;
+    // packed rows (ragged batches): utterance n owns rows row_off[n] .. + frame_len[n] of h; frame blocks beyond its end do
+    // not exist
+    const int t_end = row_off ? frame_len[n] : Tn;
+    if (t0 >= t_end) return;
+    const int64_t h_row0 = row_off ? (int64_t)row_off[n] : (int64_t)n * Tn;
 
     // ---- window DMA: rows t0 .. t0 + 255 + taps - 1 of image [g][n][Tpad][64], one contiguous block per plane ----
     const int win_rows = PC_ROWS + taps - 1;
@@ -144,8 +150,8 @@ __global__ __launch_bounds__(512, 2) void posconv_window_kernel(const T* __restr
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
         const int t = t0 + wave * 32 + mi * 16 + (lane & 15);
-        if (t >= Tn) continue;
-        float* row = h + ((int64_t)n * Tn + t) * D + g * PC_CG;
+        if (t >= t_end) continue;
+        float* row = h + (h_row0 + t) * D + g * PC_CG;
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
             const int c = ni * 16 + 4 * (lane >> 4);
@@ -165,7 +171,8 @@ __global__ __launch_bounds__(512, 2) void posconv_window_kernel(const T* __restr
 
 template <typename T, int NT>
 void launch_posconv_t(const void* image, int64_t image_plane, const void* weights, int64_t w_plane, int64_t ldw,
-                      const float* bias, float scale, float* h, int N, int Tn, int Tpad, int D, int G, int taps, hipStream_t s) {
+                      const float* bias, float scale, float* h, int N, int Tn, int Tpad, int D, int G, int taps, const int* row_off,
+                      const int* frame_len, hipStream_t s) {
     constexpr int lds = NT * PC_WIN * 128 + PC_STAGES * NT * PC_WTAP;
     static OncePerDevice attr;
     if (attr.first())
@@ -173,7 +180,7 @@ void launch_posconv_t(const void* image, int64_t image_plane, const void* weight
     const int tiles_per_utt = (Tn + PC_ROWS - 1) / PC_ROWS;
     dim3 grid((unsigned)(N * tiles_per_utt), (unsigned)G);
     hipLaunchKernelGGL((posconv_window_kernel<T, NT>), grid, dim3(512), lds, s, (const T*)image, image_plane, (const T*)weights,
-                       w_plane, ldw, bias, h, N, Tn, Tpad, D, taps, scale);
+                       w_plane, ldw, bias, h, N, Tn, Tpad, D, taps, scale, row_off, frame_len);
 }
 
 }  // namespace
@@ -198,12 +205,13 @@ bool posconv_window_eligible(int D, int G, int taps, int N, int Tn, int Tpad, in
 }
 
 void launch_posconv_window(int prec, const void* image, int64_t image_plane, const void* weights, int64_t w_plane, int64_t ldw,
-                           const float* bias, float scale, float* h, int N, int Tn, int Tpad, int D, int G, int taps, hipStream_t s) {
+                           const float* bias, float scale, float* h, int N, int Tn, int Tpad, int D, int G, int taps, const int* row_off,
+                           const int* frame_len, hipStream_t s) {
     switch (prec) {
-        case PREC_BF16: launch_posconv_t<bf16, 1>(image, image_plane, weights, w_plane, ldw, bias, scale, h, N, Tn, Tpad, D, G, taps, s); break;
-        case PREC_F16: launch_posconv_t<f16, 1>(image, image_plane, weights, w_plane, ldw, bias, scale, h, N, Tn, Tpad, D, G, taps, s); break;
-        case PREC_BF16X3: launch_posconv_t<bf16, 2>(image, image_plane, weights, w_plane, ldw, bias, scale, h, N, Tn, Tpad, D, G, taps, s); break;
-        default: launch_posconv_t<f16, 2>(image, image_plane, weights, w_plane, ldw, bias, scale, h, N, Tn, Tpad, D, G, taps, s); break;
+        case PREC_BF16: launch_posconv_t<bf16, 1>(image, image_plane, weights, w_plane, ldw, bias, scale, h, N, Tn, Tpad, D, G, taps, row_off, frame_len, s); break;
+        case PREC_F16: launch_posconv_t<f16, 1>(image, image_plane, weights, w_plane, ldw, bias, scale, h, N, Tn, Tpad, D, G, taps, row_off, frame_len, s); break;
+        case PREC_BF16X3: launch_posconv_t<bf16, 2>(image, image_plane, weights, w_plane, ldw, bias, scale, h, N, Tn, Tpad, D, G, taps, row_off, frame_len, s); break;
+        default: launch_posconv_t<f16, 2>(image, image_plane, weights, w_plane, ldw, bias, scale, h, N, Tn, Tpad, D, G, taps, row_off, frame_len, s); break;
     }
 }
 

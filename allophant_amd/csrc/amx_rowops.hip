@@ -288,11 +288,18 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
                                                       const float* __restrict__ g1, const float* __restrict__ b1, int gelu,
                                                       const float* __restrict__ g2, const float* __restrict__ b2,
                                                       float eps1, float eps2, T* __restrict__ out_p, int64_t out_plane,
-                                                      int64_t ldp, float* __restrict__ out_f32, int64_t ldo) {
+                                                      int64_t ldp, float* __restrict__ out_f32, int64_t ldo,
+                                                      const int* __restrict__ row_off, const int* __restrict__ frame_len, int T_rows) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const float* src = x + row * ldx;
+    if (row_off) {
+        // ragged batch: input row n * T_rows + t goes to packed row row_off[n] + t; frames beyond the utterance are dropped
+        const int n = (int)(row / T_rows), t = (int)(row - (int64_t)n * T_rows);
+        if (t >= frame_len[n]) return;
+        row = (int64_t)row_off[n] + t;
+    }
     float4 v[4];
     const float invD = 1.0f / (float)D;
 #pragma unroll
@@ -364,7 +371,8 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
 // ----------------------------------------------------------------------------------------------------------------
 template <typename T, int NT>
 __global__ __launch_bounds__(256) void posconv_pack_kernel(const float* __restrict__ h, int N, int Tn, int D, int G,
-                                                           int pad_front, int Tpad, T* __restrict__ out, int64_t out_plane) {
+                                                           int pad_front, int Tpad, T* __restrict__ out, int64_t out_plane,
+                                                           const int* __restrict__ row_off, const int* __restrict__ frame_len) {
     const int cg = D / G;
     const int64_t total4 = (int64_t)G * N * Tpad * cg / 4;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
@@ -377,7 +385,11 @@ __global__ __launch_bounds__(256) void posconv_pack_kernel(const float* __restri
         int g = (int)(r / N);
         int t = tp - pad_front;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t >= 0 && t < Tn) v = *(const float4*)(h + ((int64_t)n * Tn + t) * D + g * cg + ci);
+        // packed rows (row_off): utterance n owns rows row_off[n] .. + frame_len[n]; its other frames are the zeros the
+        // feature projection's row mask leaves in the padded layout
+        if (row_off) {
+            if (t >= 0 && t < frame_len[n]) v = *(const float4*)(h + ((int64_t)row_off[n] + t) * D + g * cg + ci);
+        } else if (t >= 0 && t < Tn) v = *(const float4*)(h + ((int64_t)n * Tn + t) * D + g * cg + ci);
         T hi[4], lo[4];
         split16<T, NT>(v.x, hi[0], lo[0]);
         split16<T, NT>(v.y, hi[1], lo[1]);
@@ -558,7 +570,8 @@ __global__ __launch_bounds__(256) void time_attention_kernel(const float* __rest
 __global__ __launch_bounds__(256) void logsoftmax_out_kernel(const OutDesc* __restrict__ descs, int n_out,
                                                              const float* __restrict__ logits, int64_t ld, int N, int T,
                                                              const int* __restrict__ frame_len, int log_probs,
-                                                             float* __restrict__ out, int* __restrict__ nonfinite) {
+                                                             float* __restrict__ out, int* __restrict__ nonfinite,
+                                                             const int* __restrict__ row_off) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // row = n*T + t
     if (row >= (int64_t)N * T) return;
@@ -571,7 +584,7 @@ __global__ __launch_bounds__(256) void logsoftmax_out_kernel(const OutDesc* __re
         }
         return;
     }
-    const float* src_row = logits + row * ld;
+    const float* src_row = logits + (row_off ? (int64_t)row_off[n] + t : row) * ld;  // packed rows: utterances back to back
     if (nonfinite) {
         // range check of the 16-bit planes (fp16 overflows at 65504): whatever overflowed upstream has become an infinity or
         // a NaN in this frame's logits by now (amx_check_finite reads the counter)
@@ -868,14 +881,22 @@ void launch_rownorm(int prec, const float* x, int64_t ldx, int64_t M, int D, con
                     int64_t out_plane, int64_t ldp, float* out_f32, int64_t ldo, hipStream_t s) {
     dim3 grid((unsigned)((M + 3) / 4));
     AMX_DISPATCH(prec, hipLaunchKernelGGL((rownorm_kernel<T16, NT>), grid, dim3(256), 0, s, x, ldx, M, D, gamma1, beta1, gelu,
-                                          gamma2, beta2, eps1, eps2, (T16*)out_p, out_plane, ldp, out_f32, ldo));
+                                          gamma2, beta2, eps1, eps2, (T16*)out_p, out_plane, ldp, out_f32, ldo, nullptr, nullptr, 1));
+}
+
+void launch_rownorm_to_packed(int prec, const float* x, int64_t ldx, int64_t M, int D, const float* gamma1, const float* beta1,
+                              int gelu, const float* gamma2, const float* beta2, float eps1, float eps2, void* out_p,
+                              int64_t out_plane, int64_t ldp, const int* row_off, const int* frame_len, int T_rows, hipStream_t s) {
+    dim3 grid((unsigned)((M + 3) / 4));
+    AMX_DISPATCH(prec, hipLaunchKernelGGL((rownorm_kernel<T16, NT>), grid, dim3(256), 0, s, x, ldx, M, D, gamma1, beta1, gelu,
+                                          gamma2, beta2, eps1, eps2, (T16*)out_p, out_plane, ldp, nullptr, 0, row_off, frame_len, T_rows));
 }
 
 void launch_posconv_pack(int prec, const float* h, int N, int T, int D, int G, int pad_front, int Tpad, void* out,
-                         int64_t out_plane, hipStream_t s) {
+                         int64_t out_plane, const int* row_off, const int* frame_len, hipStream_t s) {
     int64_t total4 = (int64_t)N * Tpad * D / 4;
     AMX_DISPATCH(prec, hipLaunchKernelGGL((posconv_pack_kernel<T16, NT>), dim3(grid_for(total4)), dim3(256), 0, s, h, N, T, D,
-                                          G, pad_front, Tpad, (T16*)out, out_plane));
+                                          G, pad_front, Tpad, (T16*)out, out_plane, row_off, frame_len));
 }
 
 void launch_concat(int prec, const ConcatPart* parts_dev, int n_parts, const float* logits, int64_t ld_logits, int64_t M,
@@ -913,10 +934,10 @@ void launch_time_attention(int prec, const float* qkv, const int* frame_len, int
 }
 
 void launch_logsoftmax_out(const OutDesc* descs_dev, int n_out, const float* logits, int64_t ld, int N, int T,
-                           const int* frame_len, int log_probs, float* out, int* nonfinite, hipStream_t s) {
+                           const int* frame_len, int log_probs, float* out, int* nonfinite, const int* row_off, hipStream_t s) {
     int64_t M = (int64_t)N * T;
     hipLaunchKernelGGL(logsoftmax_out_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, descs_dev, n_out, logits, ld,
-                       N, T, frame_len, log_probs, out, nonfinite);
+                       N, T, frame_len, log_probs, out, nonfinite, row_off);
 }
 
 void launch_greedy_ctc(const OutDesc* descs_dev, int n_out, const float* out, const int* frame_len, int N, int T,
