@@ -3,9 +3,10 @@
 The reference stores ``Checkpoint.Schema().dump(checkpoint)`` with ``torch.save``: a plain dict with the fields
 ``config, allophant_version, feature_size, sample_rate, attribute_graph{nodes, node_indices, edges}, epoch,
 phonetic_indexer_state, dataset_meta_data, model_state, additional, history, optimization_states``.  Only the fields that
-shape the prediction path are read here; the encoder shape is XLS-R-300m (``nn.acoustic_model.model_id``,
-default_config.toml:34-37) unless the checkpoint carries an explicit ``additional["amx_encoder"]`` override (synthetic
-checkpoints used by the plumbing tests -- real hub checkpoints are not reachable offline).
+shape the prediction path are read here; the encoder shape and variant follow ``nn.acoustic_model.model_id`` (XLS-R-300m
+in default_config.toml:34-37 and every released checkpoint; the table ``MODEL_ID_ENCODERS`` also knows the group-norm /
+post-LN wav2vec2-base and -large) unless the checkpoint carries an explicit ``additional["amx_encoder"]`` override
+(synthetic checkpoints used by the plumbing tests -- real hub checkpoints are not reachable offline).
 
 Composition models: upstream rebuilds the embedding-table layout (``_category_offsets``, a non-persistent buffer) from the
 phonetic indexer, which itself is rebuilt from ``phonetic_indexer_state`` = {phoneme_inventory, language_allophones,
@@ -22,6 +23,27 @@ import torch
 from . import spec as _spec
 
 XLSR_MODEL_IDS = ("facebook/wav2vec2-xls-r-300m",)
+
+
+def _large_groupnorm_encoder() -> Dict[str, Any]:
+    encoder = _spec.xlsr_300m_encoder()
+    encoder.update(feat_extract_norm="group", conv_bias=False, stable_layer_norm=False, use_attention_mask=False)
+    return encoder
+
+
+# `nn.acoustic_model.model_id` -> encoder shape.  The reference reads config.json / preprocessor_config.json of whatever id
+# the config names (acoustic_model.py:775-826); the hub is unreachable offline, so the shapes of the public checkpoints are
+# tabulated here from their published configs [from memory -- an id outside this table needs `additional["amx_encoder"]`
+# or the live-model binding `spec.spec_from_reference_model`, which reads the real config objects].
+MODEL_ID_ENCODERS = {
+    "facebook/wav2vec2-xls-r-300m": _spec.xlsr_300m_encoder,           # every released Allophant checkpoint
+    "facebook/wav2vec2-large-xlsr-53": _spec.xlsr_300m_encoder,        # same shape and variant (layer norm, pre-LN, mask)
+    "facebook/wav2vec2-large-lv60": _spec.xlsr_300m_encoder,
+    "facebook/wav2vec2-base": _spec.wav2vec2_base_encoder,             # group norm, post-LN, return_attention_mask=False
+    "facebook/wav2vec2-large": _large_groupnorm_encoder,
+}
+ENCODER_KEYS = ("conv_dim", "conv_kernel", "conv_stride", "hidden", "layers", "heads", "ffn", "pos_kernel", "pos_groups", "eps",
+                "do_normalize", "feat_extract_norm", "conv_bias", "stable_layer_norm", "use_attention_mask")
 
 
 def _time_config(c: Dict[str, Any]) -> Optional[Dict[str, Any]]:
@@ -57,16 +79,14 @@ def make_checkpoint(spec: Dict[str, Any], state_dict: Dict[str, torch.Tensor], s
     }
     additional: Dict[str, Any] = {}
     if synthetic_encoder:
-        additional["amx_encoder"] = {k: spec[k] for k in (
-            "conv_dim", "conv_kernel", "conv_stride", "hidden", "layers", "heads", "ffn", "pos_kernel", "pos_groups", "eps",
-            "do_normalize")}
+        additional["amx_encoder"] = {k: spec[k] for k in ENCODER_KEYS if k in spec}
     if spec.get("composition_categories") is not None and indexer_state is None:
         additional["amx_composition_categories"] = list(spec["composition_categories"])
     if spec.get("shared_phones") is not None:
         additional["amx_shared_phones"] = int(spec["shared_phones"])
     return {
         "config": {"nn": {"projection": projection,
-                          "acoustic_model": {"type": "wav2vec2-pretrained", "model_id": XLSR_MODEL_IDS[0]},
+                          "acoustic_model": {"type": "wav2vec2-pretrained", "model_id": spec.get("model_id", XLSR_MODEL_IDS[0])},
                           "loss": {"type": "CTC"}}},
         "allophant_version": "1.0.0",
         "feature_size": 1,
@@ -128,8 +148,8 @@ def spec_from_checkpoint(checkpoint: Dict[str, Any]) -> Dict[str, Any]:
     acoustic = nn_config.get("acoustic_model", {})
     if "amx_encoder" in additional:
         encoder = dict(additional["amx_encoder"])
-    elif acoustic.get("model_id") in XLSR_MODEL_IDS:
-        encoder = _spec.xlsr_300m_encoder()
+    elif acoustic.get("model_id") in MODEL_ID_ENCODERS:
+        encoder = MODEL_ID_ENCODERS[acoustic["model_id"]]()
     else:
         raise ValueError(f"Unsupported model type: {acoustic.get('type')!r} / {acoustic.get('model_id')!r}")
     projection = nn_config["projection"]

@@ -66,6 +66,10 @@ struct amx_handle_s {
 
     // weights
     float *c0_w = nullptr, *c0_b = nullptr;
+    // the variant of the wav2vec 2.0 encoder (amx_config ABI 4)
+    bool gn = false;         // feat_extract_norm == "group": GroupNorm over time behind conv layer 0, no norm behind layers 1..
+    bool stable = true;      // do_stable_layer_norm: pre-LN layers + final LayerNorm; false: post-LN layers
+    bool masked = true;      // the model is called with the attention mask of the lengths; false: attention_mask=None
     float* conv_b[AMX_MAX_CONV] = {};
     float* conv_g[AMX_MAX_CONV] = {};
     float* conv_be[AMX_MAX_CONV] = {};
@@ -154,6 +158,10 @@ struct amx_handle_s {
     bool qkv_dirty = false;
     int64_t last_L = 0, last_T = 0;
     bool last_keep = false;
+    // the last forward pass ran its heads on the packed rows of a ragged batch (packed_early): hidden states kept for
+    // OUTPUT_i classifiers, the final hidden state and the logits hold sum(frames) rows, utterance n at last_rowoff[n]
+    bool last_packed_rows = false;
+    std::vector<int> last_rowoff, last_frames;
 };
 
 namespace {
@@ -359,6 +367,8 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
         return fail(nullptr, AMX_EINVAL, "hidden / pos_groups must be a multiple of 8 and <= 64");
     if (cfg->ffn % 8) return fail(nullptr, AMX_EINVAL, "ffn must be a multiple of 8");
     if (cfg->precision < 0 || cfg->precision > 3) return fail(nullptr, AMX_EINVAL, "unknown precision");
+    if (cfg->feat_extract_norm != AMX_NORM_LAYER && cfg->feat_extract_norm != AMX_NORM_GROUP)
+        return fail(nullptr, AMX_EINVAL, "`feat_extract_norm` has to be one of ['group', 'layer']");
     if (cfg->embedding_size % 8) return fail(nullptr, AMX_EINVAL, "embedding_size must be a multiple of 8");
     if (n_classes < 1) return fail(nullptr, AMX_EINVAL, "Each model needs at least one classifier");
 
@@ -373,6 +383,9 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
     h->cfg = *cfg;
     h->prec = cfg->precision;
     h->NT = prec_planes(cfg->precision);
+    h->gn = cfg->feat_extract_norm == AMX_NORM_GROUP;
+    h->stable = cfg->stable_layer_norm != 0;
+    h->masked = cfg->use_attention_mask != 0;
     {
         static const bool plain = getenv("AMX_PLAIN_PLANES") && atoi(getenv("AMX_PLAIN_PLANES")) != 0;  // developer A/B switch
         h->il = h->NT > 1 && !plain && cfg->conv_dim % 32 == 0 && cfg->ffn % 32 == 0;
@@ -441,9 +454,19 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
         for (int i = 0; i < cfg->n_conv; ++i) {
             p = AM + "feature_extractor.conv_layers." + std::to_string(i) + ".";
             int k = cfg->conv_kernel[i];
-            TRY(upload_f32(h, tm, p + "conv.bias", C, &h->conv_b[i]));
-            TRY(upload_f32(h, tm, p + "layer_norm.weight", C, &h->conv_g[i]));
-            TRY(upload_f32(h, tm, p + "layer_norm.bias", C, &h->conv_be[i]));
+            if (cfg->conv_bias) {
+                TRY(upload_f32(h, tm, p + "conv.bias", C, &h->conv_b[i]));
+            } else {
+                // config.conv_bias = False (wav2vec2-base / -large): nn.Conv1d(bias=False) -- a zero bias for the kernels
+                h->conv_b[i] = (float*)dev_alloc(h, (size_t)C * 4);
+                if (!h->conv_b[i] || hipMemset(h->conv_b[i], 0, (size_t)C * 4) != hipSuccess) { h->err = "device allocation failed"; return bail(AMX_ENOMEM); }
+            }
+            // "layer": LayerNorm(C) behind every conv layer; "group": GroupNorm(C, C) behind layer 0 only -- the same key names
+            // (`layer_norm.{weight,bias}`, transformers Wav2Vec2GroupNormConvLayer / Wav2Vec2NoLayerNormConvLayer)
+            if (!h->gn || i == 0) {
+                TRY(upload_f32(h, tm, p + "layer_norm.weight", C, &h->conv_g[i]));
+                TRY(upload_f32(h, tm, p + "layer_norm.bias", C, &h->conv_be[i]));
+            }
             if (i > 0) {
                 const amx_tensor* t = tm.get(p + "conv.weight");
                 if (!t || t->numel != (int64_t)C * c_in * k) { h->err = "missing or mis-shaped tensor " + p + "conv.weight"; return bail(AMX_EINVAL); }
@@ -1017,7 +1040,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             }
             HIPCHK(h, hipHostMalloc((void**)&h->h_lengths_pinned[i], (size_t)N * 8));
             HIPCHK(h, hipHostMalloc((void**)&h->h_frames_pinned[i], (size_t)N * 4));
-            HIPCHK(h, hipHostMalloc((void**)&h->h_rowoff_pinned[i], (size_t)(2 * N + 1) * 4));  // offsets, then the order
+            HIPCHK(h, hipHostMalloc((void**)&h->h_rowoff_pinned[i], (size_t)(3 * N + 1) * 4));  // offsets, the order, encoder frames
             if (!h->pin_event[i]) HIPCHK(h, hipEventCreateWithFlags(&h->pin_event[i], hipEventDisableTiming));
             h->pin_busy[i] = false;
         }
@@ -1053,6 +1076,12 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         for (int n = 0; n < N; ++n) order[n] = n;
         std::stable_sort(order, order + N, [&](int a, int b) { return pin_frames[a] > pin_frames[b]; });
     }
+    // The frames the ENCODER treats as valid: the utterance's own, or -- a model whose preprocessor has
+    // return_attention_mask = False is called with attention_mask=None (acoustic_model.py:814,842-846) -- every frame of the
+    // padded length: nothing is zeroed, every key is attended to.  `Predictions.lengths` are the utterance's own either way.
+    const bool masked = h->masked;
+    for (int n = 0; n < N; ++n) pin_rowoff[2 * N + 1 + n] = masked ? pin_frames[n] : T;
+    if (!masked) Mp = M;  // no padding as far as the encoder is concerned: nothing to pack, nothing to skip
 
     // ---- workspace ----
     void *d_len, *d_frames, *d_partial, *d_stats, *actA, *actB, *preln, *hbuf, *xp, *hg, *qb, *kb, *vtb, *ao, *ff, *hfin, *logits;
@@ -1074,7 +1103,8 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     WS("len", (size_t)N * 8, d_len);
     WS("frames", (size_t)N * 4, d_frames);
     void* d_rowoff;
-    WS("rowoff", (size_t)(2 * N + 1) * 4, d_rowoff);
+    WS("rowoff", (size_t)(3 * N + 1) * 4, d_rowoff);
+    const int* d_frames_enc = (const int*)d_rowoff + 2 * N + 1;
     WS("partial", (size_t)N * 64 * 3 * 8, d_partial);
     WS("stats", (size_t)N * 2 * 4, d_stats);
     WS("actA", (size_t)rows1 * C * 2 * NT + PLANE_SLACK, actA);
@@ -1100,14 +1130,8 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     static const bool no_pack_env = getenv("AMX_NO_PACKED_ROWS") && atoi(getenv("AMX_NO_PACKED_ROWS")) != 0;
     const bool any_hidden = keep;  // the debug capture wants every hidden state in the padded layout, padding included
     const int TpTot = round_up((int)Mp, 64) + 64;  // rows per head of the packed Q / K / V planes
-    const bool packed = !no_pack_env && !(flags & AMX_FLAG_NO_PACK) && !any_hidden && D % 4 == 0 && Mp * 10 <= M * 9 &&
-                        (int64_t)TpTot <= (int64_t)N * Tp;
-    // K/V/Q padding rows [T, Tp) must stay finite: re-zero when the geometry changes
-    if (!packed && (h->last_N != N || h->last_T != T || h->qkv_dirty)) {
-        HIPCHK(h, hipMemsetAsync(qb, 0, qkv_bytes, s));
-        HIPCHK(h, hipMemsetAsync(kb, 0, qkv_bytes, s));
-        HIPCHK(h, hipMemsetAsync(vtb, 0, qkv_bytes, s));
-    }
+    bool packed = !no_pack_env && !(flags & AMX_FLAG_NO_PACK) && !any_hidden && D % 4 == 0 && Mp * 10 <= M * 9 &&
+                  (int64_t)TpTot <= (int64_t)N * Tp;
     // Packed from the feature projection on ("early"): the last conv layer's LayerNorm pass gathers the valid frames, so the
     // feature projection, the positional convolution (window kernel: skips the frame blocks beyond an utterance), the final
     // LayerNorm, the classifier heads and the log-softmax read packed rows too and nothing is packed or unpacked in between.
@@ -1119,7 +1143,15 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     const bool window_ok = !no_window && posconv_window_eligible(D, c.pos_groups, c.pos_kernel, N, T, Tpad, (int64_t)N * Tpad * D);
     bool any_time_layer = false;
     for (auto& st : h->steps) any_time_layer |= st.time_heads > 0;
+    // (the post-LN encoder has no LayerNorm pass between its last layer and the heads to unpack behind: it packs early or not at all)
+    if (!h->stable && !(window_ok && !any_time_layer && !late_pack)) packed = false;
     const bool packed_early = packed && window_ok && !any_time_layer && !late_pack;
+    // K/V/Q padding rows [T, Tp) must stay finite: re-zero when the geometry changes
+    if (!packed && (h->last_N != N || h->last_T != T || h->qkv_dirty)) {
+        HIPCHK(h, hipMemsetAsync(qb, 0, qkv_bytes, s));
+        HIPCHK(h, hipMemsetAsync(kb, 0, qkv_bytes, s));
+        HIPCHK(h, hipMemsetAsync(vtb, 0, qkv_bytes, s));
+    }
     void* hpk = nullptr;
     if (packed) {
         WS("h_packed", (size_t)Mp * D * 4, hpk);
@@ -1157,7 +1189,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
 
     HIPCHK(h, hipMemcpyAsync(d_len, pin_len, (size_t)N * 8, hipMemcpyHostToDevice, s));
     HIPCHK(h, hipMemcpyAsync(d_frames, pin_frames, (size_t)N * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(h, hipMemcpyAsync(d_rowoff, pin_rowoff, (size_t)(2 * N + 1) * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(d_rowoff, pin_rowoff, (size_t)(3 * N + 1) * 4, hipMemcpyHostToDevice, s));
     // Ragged batch: the conv stack skips what lies wholly in an utterance's padding (conv0: frame blocks; the row-complete
     // layers 1..n-2: 128-row tiles).  A valid frame of any layer only reads valid frames of the layer below, and the rows
     // left unwritten (stale, possibly non-finite) stay inside padded rows until the feature projection zeroes those.
@@ -1197,13 +1229,27 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     HIPCHK(h, hipEventRecord(h->pin_event[slot], s));
     h->pin_busy[slot] = true;
 
-    // amx_check_finite reports on THIS forward pass; the slices of one over-long batch (AMX_FLAG_PADDED) add up
-    if (!(flags & AMX_FLAG_PADDED)) HIPCHK(h, hipMemsetAsync(h->nonfinite, 0, 4, s));
+    // amx_check_finite reports on THIS forward pass; the later slices of one over-long batch (AMX_FLAG_CONTINUE) add up
+    if (!(flags & AMX_FLAG_CONTINUE)) HIPCHK(h, hipMemsetAsync(h->nonfinite, 0, 4, s));
     // ---- input normalisation statistics + conv layer 0 (fused norm + conv + LN + GELU) ----
     { Timed t_(h, AMX_KC_OTHER); launch_audio_stats(d_audio, (const int64_t*)d_len, N, L, (double*)d_partial, (float*)d_stats, c.do_normalize, s); }
-    { Timed t_(h, AMX_KC_CONV0); launch_conv0(prec, d_audio, (const int64_t*)d_len, (const float*)d_stats, N, L, (int)Ts[1], C, c.conv_kernel[0],
-                 c.conv_stride[0], h->c0_w, h->conv_b[0], h->conv_g[0], h->conv_be[0], 1e-5f, c.do_normalize, actA,
-                 pln(h, rows1 * C), ragged ? 1 : 0, s); }
+    if (h->gn) {
+        // group-norm variant: GroupNorm statistics over ALL frames of the padded length (upstream normalises the padded batch
+        // tensor), then conv + affine + GELU; frame blocks in an utterance's padding may still be skipped in the second pass
+        void *gn_partial, *gn_scale, *gn_shift;
+        WS("gn_partial", conv0_groupnorm_partial_bytes(N, (int)Ts[1], C), gn_partial);
+        WS("gn_scale", (size_t)N * C * 4, gn_scale);
+        WS("gn_shift", (size_t)N * C * 4, gn_shift);
+        Timed t_(h, AMX_KC_CONV0);
+        launch_conv0_groupnorm(prec, d_audio, (const int64_t*)d_len, (const float*)d_stats, N, L, (int)Ts[1], C, c.conv_kernel[0],
+                               c.conv_stride[0], h->c0_w, h->conv_b[0], h->conv_g[0], h->conv_be[0], 1e-5f, c.do_normalize,
+                               (double*)gn_partial, (float*)gn_scale, (float*)gn_shift, actA, pln(h, rows1 * C), ragged ? 1 : 0, s);
+    } else {
+        Timed t_(h, AMX_KC_CONV0);
+        launch_conv0(prec, d_audio, (const int64_t*)d_len, (const float*)d_stats, N, L, (int)Ts[1], C, c.conv_kernel[0],
+                     c.conv_stride[0], h->c0_w, h->conv_b[0], h->conv_g[0], h->conv_be[0], 1e-5f, c.do_normalize, actA,
+                     pln(h, rows1 * C), ragged ? 1 : 0, s);
+    }
     // ---- conv layers 1..n-1: implicit GEMM over overlapping channels-last windows, then LN + GELU rows ----
     void* cur = actA;
     int64_t cur_plane = pln(h, rows1 * C);
@@ -1222,6 +1268,29 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         }
         const bool last = i == c.n_conv - 1;
         const int64_t out_plane = pln(h, rows_out * C);
+        if (h->gn) {
+            // group-norm variant: conv + GELU, no norm (Wav2Vec2NoLayerNormConvLayer): the GELU sits in the product's epilogue
+            g.act = 1;
+            g.tile_list = nullptr; g.n_tiles = 0;
+            if (!last) {
+                g.out_p = other; g.out_plane = out_plane; g.ldp = C;
+                { Timed t_(h, gemm_class(prec, g)); run_gemm(prec, g, s); }
+            } else {
+                // last layer: fp32 GELU output, then the feature-projection LayerNorm -> planes (packed_early: valid frames only)
+                g.out_f32 = keep ? conv_dbg : (float*)preln; g.ldo = C;
+                { Timed t_(h, AMX_KC_CONV_TAIL); run_gemm(prec, g, s); }
+                Timed t_(h, AMX_KC_CONV_TAIL);
+                if (packed_early)
+                    launch_rownorm_to_packed(prec, g.out_f32, C, rows_out, C, nullptr, nullptr, 0, h->fp_g, h->fp_b, 0.f, c.eps, other,
+                                             out_plane, C, (const int*)d_rowoff, (const int*)d_frames, T, s);
+                else
+                    launch_rownorm(prec, g.out_f32, C, rows_out, C, nullptr, nullptr, 0, h->fp_g, h->fp_b, 0.f, c.eps, other, out_plane,
+                                   C, nullptr, 0, s);
+            }
+            std::swap(cur, other);
+            cur_plane = out_plane;
+            continue;
+        }
         if (!last) {
             // LayerNorm + GELU fused into the GEMM epilogue when the row-complete kernel takes the shape (C == 512)
             GemmParams f = g;
@@ -1268,7 +1337,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         g.W = h->fp_w; g.w_plane = pln(h, (int64_t)D * C); g.ldw = C;
         g.M = (int)Mfp; g.N = D; g.K = C;
         g.scale = h->fp_r; g.bias = h->fp_bias;
-        if (!packed_early) { g.row_len = (const int*)d_frames; g.rows_T = T; }
+        if (!packed_early && masked) { g.row_len = (const int*)d_frames; g.rows_T = T; }  // hidden_states[~mask] = 0
         g.out_f32 = (float*)(packed_early ? hpk : hbuf); g.ldo = D;
         { Timed t_(h, gemm_class(prec, g)); run_gemm(prec, g, s); }
     }
@@ -1334,9 +1403,15 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             launch_rownorm(prec, (const float*)hbuf, D, rows, D, gamma, beta, 0, nullptr, nullptr, c.eps, 0.f, xp, plane, D, out_ln, D, s);
         }
     };
+    const bool stable = h->stable;
+    // post-LN encoder (Wav2Vec2Encoder): h = LayerNorm(h + pos_conv(h)) first; every layer is h = LN1(h + attention(h)),
+    // h = LN2(h + FFN(h)); hidden_states[layers] is the last layer's output as it is.  The LayerNorm passes write the fp32
+    // rows back in place (the residual stream IS the normalised tensor) next to the planes the products read.
+    float* const ln_inplace = stable ? nullptr : (float*)hbuf;
+    if (!stable) stream_norm(h->fln_g, h->fln_b, Mrows, xp_plane, ln_inplace);
     for (int l = 0; l < c.layers; ++l) {
         const Layer& ly = h->layers[l];
-        stream_norm(ly.ln1_g, ly.ln1_b, Mrows, xp_plane, nullptr);  // (completes the previous layer's FFN2 when that was deferred)
+        if (stable) stream_norm(ly.ln1_g, ly.ln1_b, Mrows, xp_plane, nullptr);  // (completes the previous layer's FFN2 when that was deferred)
         if (saved[l]) {
             // a classifier reads hidden state l (OUTPUT_l, acoustic_model.py:478-483): padded layout; with packed rows the padded
             // frames take their pre-encoder rows (finite, as meaningless as any padded frame) and the valid ones are scattered in
@@ -1365,7 +1440,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             a.q = qb; a.k = kb; a.v = vtb;
             a.qk_plane = qk_plane;
             a.out = ao; a.out_plane = xp_plane;
-            a.frame_len = (const int*)d_frames;
+            a.frame_len = d_frames_enc;
             a.N = N; a.H = H; a.T = T; a.Tp = packed ? TpTot : Tp; a.dh = 64;
             a.row_off = packed ? (const int*)d_rowoff : nullptr;
             a.order = packed ? (const int*)d_rowoff + N + 1 : nullptr;
@@ -1380,7 +1455,9 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             g.residual = (const float*)hbuf; g.ldr = D; g.out_f32 = (float*)hbuf; g.ldo = D;
             residual_gemm(g, true);
         }
-        stream_norm(ly.ln2_g, ly.ln2_b, Mrows, xp_plane, nullptr);
+        // pre-LN: the LayerNorm in front of the FFN (`final_layer_norm`); post-LN: `layer_norm` behind the attention residual
+        if (stable) stream_norm(ly.ln2_g, ly.ln2_b, Mrows, xp_plane, nullptr);
+        else stream_norm(ly.ln1_g, ly.ln1_b, Mrows, xp_plane, ln_inplace);
         {
             GemmParams g{};
             g.A = xp; g.a_plane = xp_plane; g.lda = D; g.rows_per_batch = Mrows;
@@ -1400,6 +1477,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             // (the last layer of a packed batch is followed by the unpacking, not by a LayerNorm of these rows)
             residual_gemm(g, !(packed && !packed_early && l == c.layers - 1));
         }
+        if (!stable) stream_norm(ly.ln2_g, ly.ln2_b, Mrows, xp_plane, ln_inplace);  // `final_layer_norm` closes the post-LN layer
     }
     if (packed && !packed_early) {
         // back to the padded layout for the final LayerNorm and the projection (padded frames keep their pre-encoder rows)
@@ -1407,7 +1485,14 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         hbuf = hpad;
     }
     const int64_t Mh = packed_early ? Mp : M;  // rows of the final LayerNorm and of the classifier heads
-    stream_norm(h->fln_g, h->fln_b, Mh, pln(h, Mh * D), (float*)hfin);
+    if (stable) {
+        stream_norm(h->fln_g, h->fln_b, Mh, pln(h, Mh * D), (float*)hfin);
+    } else {
+        // post-LN: hidden_states[layers] = the stream as the last layer left it; its planes are in xp already
+        if (keep) HIPCHK(h, hipMemcpyAsync(hfin, hbuf, (size_t)Mh * D * 4, hipMemcpyDeviceToDevice, s));
+        else hfin = hbuf;
+        saved[c.layers] = (float*)hfin;
+    }
 
     // ---- hierarchical projection ----
     const int E = c.embedding_size;
@@ -1515,6 +1600,11 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         HIPCHK(h, hipStreamSynchronize(s));
     }
     h->last_N = N; h->last_L = L; h->last_T = T; h->last_keep = keep;
+    h->last_packed_rows = packed_early;
+    if (packed_early) {
+        h->last_rowoff.assign(pin_rowoff, pin_rowoff + N);
+        h->last_frames.assign(pin_frames, pin_frames + N);
+    }
     h->qkv_dirty = packed;  // a packed call leaves other rows in the Q / K / V planes: the next padded call re-zeroes them
 #undef WS
     return AMX_OK;
@@ -1531,10 +1621,13 @@ extern "C" int amx_synchronize(amx_handle h, void* stream) {
 extern "C" int amx_check_finite(amx_handle h, void* stream, int64_t* frames) {
     if (!h) return AMX_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+    hipStream_t s = (hipStream_t)stream;
     int count = 0;
-    HIPCHK(h, hipMemcpy(&count, h->nonfinite, 4, hipMemcpyDeviceToHost));
-    HIPCHK(h, hipMemset(h->nonfinite, 0, 4));  // a check closes its reporting period
+    // read and reset IN STREAM ORDER: callers pass non-blocking streams, which the null stream does not order against, so a
+    // reset on the null stream could land after a later forward pass had started counting
+    HIPCHK(h, hipMemcpyAsync(&count, h->nonfinite, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemsetAsync(h->nonfinite, 0, 4, s));  // a check closes its reporting period
+    HIPCHK(h, hipStreamSynchronize(s));
     if (frames) *frames = count;
     if (count > 0)
         return fail(h, AMX_ERANGE, std::to_string(count) + " valid frame(s) of the last forward pass hold non-finite logits: an activation left the "
@@ -1609,6 +1702,8 @@ extern "C" int amx_debug_fetch(amx_handle h, int what, int index, float* host_ou
     } else if (what == 1) {
         if (index < 0 || index > h->cfg.layers) return fail(h, AMX_EINVAL, "hidden state index out of range");
         std::string nm = index == h->cfg.layers ? "hfin" : "hid" + std::to_string(index);
+        if (index == h->cfg.layers && !h->stable && !h->last_keep)
+            return fail(h, AMX_ESTATE, "the post-LN encoder keeps its last hidden state for the debug fetch only with AMX_FLAG_KEEP_HIDDEN");
         if (!h->ws.count(nm) || !h->ws[nm].p || (index < h->cfg.layers && !h->last_keep && !h->need_hidden[index]))
             return fail(h, AMX_ESTATE, "hidden state was not kept (AMX_FLAG_KEEP_HIDDEN)");
         src = h->ws[nm].p; n = M * h->cfg.hidden;
@@ -1628,6 +1723,20 @@ extern "C" int amx_debug_fetch(amx_handle h, int what, int index, float* host_ou
     }
     if (!src) return fail(h, AMX_ESTATE, "nothing to fetch before the first amx_forward");
     if (capacity < n) return fail(h, AMX_EINVAL, "debug buffer too small");
+    if (h->last_packed_rows && (what == 1 || what == 2)) {
+        // the buffer holds the packed rows of a ragged batch (utterance n at last_rowoff[n]): hand them out in the padded
+        // [N, T] layout the caller expects, frames beyond an utterance as zeros
+        const int64_t ld = n / M;
+        int64_t Mp = 0;
+        for (int f : h->last_frames) Mp += f;
+        std::vector<float> rows((size_t)Mp * ld);
+        HIPCHK(h, hipMemcpy(rows.data(), src, rows.size() * 4, hipMemcpyDeviceToHost));
+        std::fill(host_out, host_out + n, 0.f);
+        for (int u = 0; u < h->last_N; ++u)
+            std::memcpy(host_out + (int64_t)u * h->last_T * ld, rows.data() + (int64_t)h->last_rowoff[u] * ld,
+                        (size_t)h->last_frames[u] * ld * 4);
+        return AMX_OK;
+    }
     HIPCHK(h, hipMemcpy(host_out, src, (size_t)n * 4, hipMemcpyDeviceToHost));
     return AMX_OK;
 }

@@ -275,6 +275,15 @@ void launch_conv0(int prec, const float* audio, const int64_t* lengths, const fl
                   int C, int k, int stride, const float* w /*[C,k]*/, const float* b, const float* gamma,
                   const float* beta, float eps, int do_normalize, void* out, int64_t out_plane, int skip_padding, hipStream_t s);
 // (skip_padding: frame blocks that start beyond an utterance's own frames are not computed -- ragged batches)
+// the group-norm feature extractor (feat_extract_norm = "group"): conv layer 0 + GroupNorm(C groups) over the T1 frames of the
+// padded length + GELU.  Two passes over the audio (the k-tap conv is recomputed, never stored): per-(utterance, channel)
+// fp64 statistics into `partial` (conv0_groupnorm_partial_bytes) -> scale / shift [N, C] -> the conv0 kernel with the affine
+// form y = conv * scale + shift.  gamma / beta: the GroupNorm affine parameters [C]
+size_t conv0_groupnorm_partial_bytes(int N, int T1, int C);
+void launch_conv0_groupnorm(int prec, const float* audio, const int64_t* lengths, const float* mean_rstd, int N, int64_t L, int T1,
+                            int C, int k, int stride, const float* w, const float* b, const float* gamma, const float* beta,
+                            float eps, int do_normalize, double* partial, float* scale, float* shift, void* out, int64_t out_plane,
+                            int skip_padding, hipStream_t s);
 // rows of the padded [N, T, D] fp32 matrix <-> rows of the packed [sum(frame_len), D] matrix (utterance n at row_off[n]);
 // only rows t < frame_len[n] move
 void launch_pack_rows(const float* padded, float* packed, const int* row_off, const int* frame_len, int N, int T, int D, bool unpack,

@@ -72,7 +72,11 @@ __global__ void audio_stats_final_kernel(const double* __restrict__ partial, con
 // ----------------------------------------------------------------------------------------------------------------
 constexpr int C0_FRAMES = 128;  // frames per workgroup: amortises the per-lane weight loads
 
-template <typename T, int NT, int CPL, int KW>
+// GN (the group-norm feature extractor, `feat_extract_norm="group"`: GroupNorm(C groups of one channel) over TIME behind conv
+// layer 0 instead of a LayerNorm over channels): the statistics come from conv0_gn_stats_kernel, and `gamma` / `beta` are the
+// per-(utterance, channel) scale and shift [N, C] that conv0_gn_final_kernel folded them into -- y = acc * scale + shift, no
+// cross-lane reduction.
+template <typename T, int NT, int CPL, int KW, bool GN>
 __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ audio, const int64_t* __restrict__ lengths,
                                                     const float* __restrict__ mean_rstd, int64_t L, int T1, int C, int k,
                                                     int stride, const float* __restrict__ w, const float* __restrict__ b,
@@ -101,6 +105,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ au
     }
     const int c0 = lane * CPL;
     const bool active = c0 < C;
+    if (GN) { gamma += (int64_t)n * C; beta += (int64_t)n * C; }
     float wr[CPL][KW], br[CPL], gr[CPL], be[CPL];
     if ((CPL * KW) % 4 == 0 && k == KW && c0 + CPL <= C) {
         // this lane's CPL x KW weights are contiguous and 16-byte aligned: branch-free vector loads (the per-element
@@ -168,23 +173,28 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ au
             }
             // channels beyond C carry zero weights and bias, so they add nothing to the sums (c0 + CPL <= C or lane idle)
             float mu[FPI], rs[FPI];
+            if constexpr (!GN) {
 #pragma unroll
-            for (int u = 0; u < FPI; ++u) {
-                f32x2 s2 = acc[u][0];
+                for (int u = 0; u < FPI; ++u) {
+                    f32x2 s2 = acc[u][0];
 #pragma unroll
-                for (int i = 1; i < CP; ++i) s2 += acc[u][i];
-                mu[u] = wave_sum(active ? s2[0] + s2[1] : 0.f) * invC;
-            }
-#pragma unroll
-            for (int u = 0; u < FPI; ++u) {
-                const f32x2 m2 = {mu[u], mu[u]};
-                f32x2 q2 = {0.f, 0.f};
-#pragma unroll
-                for (int i = 0; i < CP; ++i) {
-                    const f32x2 d = acc[u][i] - m2;
-                    q2 = d * d + q2;
+                    for (int i = 1; i < CP; ++i) s2 += acc[u][i];
+                    mu[u] = wave_sum(active ? s2[0] + s2[1] : 0.f) * invC;
                 }
-                rs[u] = 1.0f / sqrtf(wave_sum(active ? q2[0] + q2[1] : 0.f) * invC + eps);
+#pragma unroll
+                for (int u = 0; u < FPI; ++u) {
+                    const f32x2 m2 = {mu[u], mu[u]};
+                    f32x2 q2 = {0.f, 0.f};
+#pragma unroll
+                    for (int i = 0; i < CP; ++i) {
+                        const f32x2 d = acc[u][i] - m2;
+                        q2 = d * d + q2;
+                    }
+                    rs[u] = 1.0f / sqrtf(wave_sum(active ? q2[0] + q2[1] : 0.f) * invC + eps);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < FPI; ++u) { mu[u] = 0.f; rs[u] = 1.f; }
             }
 #pragma unroll
             for (int u = 0; u < FPI; ++u) {
@@ -193,7 +203,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ au
                 const f32x2 r2 = {rs[u], rs[u]}, m2 = {mu[u], mu[u]};
 #pragma unroll
                 for (int i = 0; i < CP; ++i) {
-                    const f32x2 v = (acc[u][i] - m2) * r2 * g2[i] + be2[i];
+                    const f32x2 v = GN ? acc[u][i] * g2[i] + be2[i] : (acc[u][i] - m2) * r2 * g2[i] + be2[i];
                     f32x2 y = gelu_fast2(v);
                     // one register pair for y: its 16-bit image and the residual are taken from the same value (see split16)
                     asm volatile("" : "+v"(y));
@@ -240,22 +250,27 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ au
             }
         }
         float mu[FPI], rs[FPI];
+        if constexpr (!GN) {
 #pragma unroll
-        for (int u = 0; u < FPI; ++u) {
-            float s = 0.f;
+            for (int u = 0; u < FPI; ++u) {
+                float s = 0.f;
 #pragma unroll
-            for (int i = 0; i < CPL; ++i) s += (c0 + i < C) ? acc[u][i] : 0.f;
-            mu[u] = wave_sum(s) * invC;
-        }
-#pragma unroll
-        for (int u = 0; u < FPI; ++u) {
-            float q = 0.f;
-#pragma unroll
-            for (int i = 0; i < CPL; ++i) {
-                float d = acc[u][i] - mu[u];
-                q += (c0 + i < C) ? d * d : 0.f;
+                for (int i = 0; i < CPL; ++i) s += (c0 + i < C) ? acc[u][i] : 0.f;
+                mu[u] = wave_sum(s) * invC;
             }
-            rs[u] = 1.0f / sqrtf(wave_sum(q) * invC + eps);
+#pragma unroll
+            for (int u = 0; u < FPI; ++u) {
+                float q = 0.f;
+#pragma unroll
+                for (int i = 0; i < CPL; ++i) {
+                    float d = acc[u][i] - mu[u];
+                    q += (c0 + i < C) ? d * d : 0.f;
+                }
+                rs[u] = 1.0f / sqrtf(wave_sum(q) * invC + eps);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < FPI; ++u) { mu[u] = 0.f; rs[u] = 1.f; }
         }
 #pragma unroll
         for (int u = 0; u < FPI; ++u) {
@@ -277,6 +292,89 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ au
             }
         }
     }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Group-norm feature extractor (transformers Wav2Vec2GroupNormConvLayer: conv -> GroupNorm(num_groups = C) -> GELU): the
+// statistics of conv layer 0's raw output per (utterance, channel) over ALL T1 frames of the padded length -- upstream
+// normalises the padded batch tensor, so frames of an utterance's padding count (their conv output is the bias).  The conv
+// (k taps per output) is recomputed rather than stored: pass 1 here, pass 2 = conv0_kernel<GN>.  fp64 sums of the fp32 conv
+// values, fixed order (block partials, then a serial combine): deterministic.
+// ----------------------------------------------------------------------------------------------------------------
+constexpr int GN_FRAMES = 1024;  // frames per workgroup of the statistics pass
+
+template <int KW>
+__global__ __launch_bounds__(256) void conv0_gn_stats_kernel(const float* __restrict__ audio, const int64_t* __restrict__ lengths,
+                                                             const float* __restrict__ mean_rstd, int64_t L, int T1, int C, int k,
+                                                             int stride, const float* __restrict__ w, const float* __restrict__ b,
+                                                             int do_normalize, double* __restrict__ partial /*[N][blocks][C][2]*/) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* win = (float*)smem;
+    const int n = blockIdx.y, blk = blockIdx.x;
+    const int f0 = blk * GN_FRAMES;
+    const int frames = min(GN_FRAMES, T1 - f0);
+    const int nwin = (frames - 1) * stride + k;
+    const int64_t len = lengths[n];
+    const float mean = mean_rstd[2 * n], rstd = mean_rstd[2 * n + 1];
+    const int64_t s0 = (int64_t)f0 * stride;
+    for (int i = threadIdx.x; i < nwin; i += 256) {
+        const int64_t pos = s0 + i;
+        float x = 0.f;
+        if (pos < L) {
+            x = audio[(int64_t)n * L + pos];
+            if (do_normalize) x = pos < len ? (x - mean) * rstd : 0.f;
+        }
+        win[i] = x;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float wr[KW];
+#pragma unroll
+        for (int j = 0; j < KW; ++j) wr[j] = j < k ? w[c * k + j] : 0.f;
+        const float bias = b[c];
+        double s = 0.0, q = 0.0;
+        for (int f = 0; f < frames; f += 8) {
+            // eight frames in fp32, then one fp64 step: the fp32 partial sums stay short (8 terms)
+            float s8 = 0.f, q8 = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (f + u < frames) {
+                    float acc = bias;
+#pragma unroll
+                    for (int j = 0; j < KW; ++j) acc = fmaf(wr[j], j < k ? win[(f + u) * stride + j] : 0.f, acc);
+                    s8 += acc;
+                    q8 = fmaf(acc, acc, q8);
+                }
+            }
+            s += (double)s8;
+            q += (double)q8;
+        }
+        double* dst = partial + (((int64_t)n * gridDim.x + blk) * C + c) * 2;
+        dst[0] = s;
+        dst[1] = q;
+    }
+}
+
+// mean / variance over the T1 frames -> scale = gamma * rstd, shift = beta - mean * scale per (utterance, channel)
+__global__ void conv0_gn_final_kernel(const double* __restrict__ partial, int blocks, int N, int C, int T1,
+                                      const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                      float* __restrict__ scale, float* __restrict__ shift) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * C) return;
+    const int n = (int)(i / C), c = (int)(i - (int64_t)n * C);
+    double s = 0.0, q = 0.0;
+    for (int blk = 0; blk < blocks; ++blk) {
+        const double* src = partial + (((int64_t)n * blocks + blk) * C + c) * 2;
+        s += src[0];
+        q += src[1];
+    }
+    const double mean = s / (double)T1;
+    double var = q / (double)T1 - mean * mean;  // biased variance, like torch.nn.GroupNorm
+    if (var < 0) var = 0;
+    const double rs = 1.0 / sqrt(var + (double)eps);
+    const double sc = (double)gamma[c] * rs;
+    scale[i] = (float)sc;
+    shift[i] = (float)((double)beta[c] - mean * sc);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -846,7 +944,7 @@ void launch_audio_stats(const float* audio, const int64_t* lengths, int N, int64
                        do_normalize);
 }
 
-template <typename T, int NT, int KW>
+template <typename T, int NT, int KW, bool GN>
 static void conv0_launch_cpl(const float* audio, const int64_t* lengths, const float* mean_rstd, int N, int64_t L, int T1,
                              int C, int k, int stride, const float* w, const float* b, const float* gamma,
                              const float* beta, float eps, int do_normalize, void* out, int64_t out_plane, int skip_padding,
@@ -855,7 +953,7 @@ static void conv0_launch_cpl(const float* audio, const int64_t* lengths, const f
     size_t lds = (size_t)(C0_FRAMES * stride + k) * sizeof(float);
     int cpl = C >= 64 ? C / 64 : 1;
 #define C0_GO(CPL)                                                                                                  \
-    hipLaunchKernelGGL((conv0_kernel<T, NT, CPL, KW>), grid, dim3(256), lds, s, audio, lengths, mean_rstd, L, T1, C, k, \
+    hipLaunchKernelGGL((conv0_kernel<T, NT, CPL, KW, GN>), grid, dim3(256), lds, s, audio, lengths, mean_rstd, L, T1, C, k, \
                        stride, w, b, gamma, beta, eps, do_normalize, (T*)out, out_plane, skip_padding)
     if (cpl == 8) C0_GO(8);
     else if (cpl == 4) C0_GO(4);
@@ -868,11 +966,39 @@ void launch_conv0(int prec, const float* audio, const int64_t* lengths, const fl
                   int C, int k, int stride, const float* w, const float* b, const float* gamma, const float* beta,
                   float eps, int do_normalize, void* out, int64_t out_plane, int skip_padding, hipStream_t s) {
     if (k == 10) {
-        AMX_DISPATCH(prec, (conv0_launch_cpl<T16, NT, 10>(audio, lengths, mean_rstd, N, L, T1, C, k, stride, w, b, gamma, beta,
-                                                         eps, do_normalize, out, out_plane, skip_padding, s)));
+        AMX_DISPATCH(prec, (conv0_launch_cpl<T16, NT, 10, false>(audio, lengths, mean_rstd, N, L, T1, C, k, stride, w, b, gamma, beta,
+                                                                eps, do_normalize, out, out_plane, skip_padding, s)));
     } else {
-        AMX_DISPATCH(prec, (conv0_launch_cpl<T16, NT, 16>(audio, lengths, mean_rstd, N, L, T1, C, k, stride, w, b, gamma, beta,
-                                                         eps, do_normalize, out, out_plane, skip_padding, s)));
+        AMX_DISPATCH(prec, (conv0_launch_cpl<T16, NT, 16, false>(audio, lengths, mean_rstd, N, L, T1, C, k, stride, w, b, gamma, beta,
+                                                                eps, do_normalize, out, out_plane, skip_padding, s)));
+    }
+}
+
+size_t conv0_groupnorm_partial_bytes(int N, int T1, int C) {
+    return (size_t)N * ((T1 + GN_FRAMES - 1) / GN_FRAMES) * C * 2 * sizeof(double);
+}
+
+void launch_conv0_groupnorm(int prec, const float* audio, const int64_t* lengths, const float* mean_rstd, int N, int64_t L, int T1,
+                            int C, int k, int stride, const float* w, const float* b, const float* gamma, const float* beta,
+                            float eps, int do_normalize, double* partial, float* scale, float* shift, void* out, int64_t out_plane,
+                            int skip_padding, hipStream_t s) {
+    const int blocks = (T1 + GN_FRAMES - 1) / GN_FRAMES;
+    const size_t lds = (size_t)((GN_FRAMES - 1) * stride + k) * sizeof(float);
+    if (k == 10)
+        hipLaunchKernelGGL(conv0_gn_stats_kernel<10>, dim3(blocks, N), dim3(256), lds, s, audio, lengths, mean_rstd, L, T1, C, k, stride,
+                           w, b, do_normalize, partial);
+    else
+        hipLaunchKernelGGL(conv0_gn_stats_kernel<16>, dim3(blocks, N), dim3(256), lds, s, audio, lengths, mean_rstd, L, T1, C, k, stride,
+                           w, b, do_normalize, partial);
+    const int64_t nc = (int64_t)N * C;
+    hipLaunchKernelGGL(conv0_gn_final_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, partial, blocks, N, C, T1, gamma, beta,
+                       eps, scale, shift);
+    if (k == 10) {
+        AMX_DISPATCH(prec, (conv0_launch_cpl<T16, NT, 10, true>(audio, lengths, mean_rstd, N, L, T1, C, k, stride, w, b, scale, shift,
+                                                               eps, do_normalize, out, out_plane, skip_padding, s)));
+    } else {
+        AMX_DISPATCH(prec, (conv0_launch_cpl<T16, NT, 16, true>(audio, lengths, mean_rstd, N, L, T1, C, k, stride, w, b, scale, shift,
+                                                               eps, do_normalize, out, out_plane, skip_padding, s)));
     }
 }
 

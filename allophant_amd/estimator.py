@@ -149,6 +149,13 @@ def _spec_to_structs(spec: Dict[str, Any], precision: str):
     if precision not in _lib.PRECISIONS:
         raise ValueError(f"unknown precision {precision!r}; expected one of {sorted(_lib.PRECISIONS)}")
     cfg.precision = _lib.PRECISIONS[precision]
+    norm = spec.get("feat_extract_norm", "layer")
+    if norm not in ("layer", "group"):
+        raise ValueError(f"`feat_extract_norm` is {norm}, but has to be one of ['group', 'layer']")  # transformers' own message
+    cfg.feat_extract_norm = _lib.NORM_GROUP if norm == "group" else _lib.NORM_LAYER
+    cfg.conv_bias = int(bool(spec.get("conv_bias", True)))
+    cfg.stable_layer_norm = int(bool(spec.get("stable_layer_norm", True)))
+    cfg.use_attention_mask = int(bool(spec.get("use_attention_mask", True)))
 
     classes = spec["classes"]
     index = {c["name"]: i for i, c in enumerate(classes)}
@@ -330,8 +337,8 @@ class Estimator:
                 # utterances padded to the same L -- no operator mixes utterances, so the results are those of one call
                 if n_max < 1:
                     raise ValueError(f"utterances of {L} samples are too long for one forward pass")
-                # the slices add to one range-check count (`check_finite`): close the previous reporting period first
-                self._lib.amx_check_finite(self._handle, C.c_void_p(stream), None)
+                # the slices add to one range-check count (`check_finite`): the first one restarts it like any forward pass,
+                # the later ones continue it (AMX_FLAG_CONTINUE) -- launch-only, no host synchronisation
                 blocks = {d.offset: d.classes for d in descs}
                 for lo in range(0, N, n_max):
                     hi = min(N, lo + n_max)
@@ -344,7 +351,7 @@ class Estimator:
                         self._handle, C.c_void_p(audio[lo:hi].data_ptr()),
                         C.cast(slice_lengths.data_ptr(), C.POINTER(C.c_int64)), n, L,
                         C.c_void_p(part.data_ptr()), C.cast(part_lengths.data_ptr(), C.POINTER(C.c_int64)),
-                        flags | _lib.FLAG_PADDED, C.c_void_p(stream))
+                        flags | _lib.FLAG_PADDED | (_lib.FLAG_CONTINUE if lo > 0 else 0), C.c_void_p(stream))
                     _lib.check(self._lib, self._handle, code)
                     out_lengths[lo:hi] = part_lengths
                     src = 0

@@ -9,14 +9,15 @@ import ctypes as C
 import os
 from typing import Optional
 
-AMX_ABI_VERSION = 3
+AMX_ABI_VERSION = 4
 AMX_MAX_CONV = 8
 AMX_MAX_DEPS = 64
 AMX_NAME_LEN = 48
 
 AMX_OK, AMX_EINVAL, AMX_EHIP, AMX_ESTATE, AMX_ENOMEM, AMX_ERANGE = 0, -1, -2, -3, -4, -5
 PRECISIONS = {"bf16": 0, "f16": 1, "bf16x3": 2, "f16x3": 3}
-FLAG_HOST_IO, FLAG_RAW_LOGITS, FLAG_KEEP_HIDDEN, FLAG_TIMING, FLAG_PADDED, FLAG_NO_PACK = 1, 2, 4, 8, 16, 32
+FLAG_HOST_IO, FLAG_RAW_LOGITS, FLAG_KEEP_HIDDEN, FLAG_TIMING, FLAG_PADDED, FLAG_NO_PACK, FLAG_CONTINUE = 1, 2, 4, 8, 16, 32, 64
+NORM_LAYER, NORM_GROUP = 0, 1
 KERNEL_CLASSES = ["gemm_pp", "gemm_tile", "attention", "rownorm", "conv0", "other", "gemm_ln", "conv_tail"]
 DEP_OUTPUT = -1
 
@@ -43,7 +44,8 @@ class AmxConfig(C.Structure):
         ("hidden", C.c_int32), ("layers", C.c_int32), ("heads", C.c_int32), ("ffn", C.c_int32),
         ("pos_kernel", C.c_int32), ("pos_groups", C.c_int32), ("eps", C.c_float), ("do_normalize", C.c_int32),
         ("dependency_blanks", C.c_int32), ("embedding_size", C.c_int32), ("allophone_layer", C.c_int32),
-        ("precision", C.c_int32),
+        ("precision", C.c_int32), ("feat_extract_norm", C.c_int32), ("conv_bias", C.c_int32),
+        ("stable_layer_norm", C.c_int32), ("use_attention_mask", C.c_int32),
     ]
 
 

@@ -135,6 +135,20 @@ class PendingGather:
         return result
 
 
+class _CompletedGather:
+    """A gather that has already completed (the padded fallback of ``DataParallelRunner``), parked in the runner's pending
+    slot so that its result is handed out by the NEXT ``step()`` / ``drain()``, after the result of the step before it."""
+
+    counted = True  # `DataParallelRunner.completed` already includes it
+
+    def __init__(self, result: Optional[Predictions]):
+        self._result = result
+
+    def wait(self) -> Optional[Predictions]:
+        result, self._result = self._result, None
+        return result
+
+
 def gather_flat_predictions(local: Predictions, device: torch.device, dst: int = 0, group=None, async_op: bool = False):
     """Fast path for equal-shaped shards (every rank ran the same ``(N, L)`` geometry, e.g. the weak-scaling benchmark):
     the outputs of ``Estimator.predict`` are views of one flat fp32 block, so a single ``gather`` of that block (plus one
@@ -183,10 +197,15 @@ class DataParallelRunner:
     ``Predictions`` of the most recently COMPLETED gather (the previous step when overlapping), ``None`` elsewhere / before
     the first completion.
 
+    Every step's predictions come out exactly once and in step order: when an overlapped step has to fall back to the padded
+    gather while the previous step's flat gather is still in flight, ``step`` returns the PREVIOUS step's result and parks
+    its own (already complete) result, which the next ``step()`` / ``drain()`` returns.
+
     ``flat=True`` is the fast path for shards of one common ``(N, L)`` geometry; every step first agrees on that with one
     small ``all_reduce`` (a rank whose shard is empty or shaped differently would otherwise leave the others hanging in a
     mismatched ``gather``) and falls back to the padded gather when the shards differ.  The padded gather needs
-    ``total_utterances`` and, because a rank with an empty shard (``local_batch=None``) has no local prediction to read
+    ``total_utterances`` (constructor default, or per step: ``step(batch, total_utterances=...)`` -- the last batch of a
+    corpus is usually smaller) and, because a rank with an empty shard (``local_batch=None``) has no local prediction to read
     them from, ``outputs`` = the distinct outputs as (name, classes) in output order and ``aliases`` (see
     ``unique_outputs``) -- or at least one earlier non-empty step on this rank to learn them from.  The agreement reads
     two integers back per step, i.e. the host waits for the step it has just enqueued; a caller that has established equal
@@ -215,27 +234,41 @@ class DataParallelRunner:
         lo_size, lo_count = -int(probe[1]), -int(probe[3])
         return lo_size >= 0 and lo_size == int(probe[0]) and lo_count == int(probe[2])
 
-    def _padded(self, local: Optional[Predictions]) -> Optional[Predictions]:
+    def _padded(self, local: Optional[Predictions], total: Optional[int]) -> Optional[Predictions]:
         if local is not None and self._outputs is None:
             self._outputs, self._aliases = unique_outputs(local)
         if self._outputs is None:
             raise ValueError("a rank with an empty shard needs `outputs` (and `aliases`): it has no local prediction to take "
                              "the output names and widths from")
-        if self._total is None:
+        if total is None:
             raise ValueError("shards of different shapes need the padded gather: pass total_utterances")
-        result = gather_predictions(local, self._outputs, self._total, self._device, dst=self._dst, group=self._group,
+        result = gather_predictions(local, self._outputs, total, self._device, dst=self._dst, group=self._group,
                                     aliases=self._aliases)
         self.completed += 1
         return result
 
-    def step(self, local_batch: Optional[Batch]) -> Optional[Predictions]:
+    def _finish(self, pending) -> Optional[Predictions]:
+        if not getattr(pending, "counted", False):
+            self.completed += 1
+        return pending.wait()
+
+    def step(self, local_batch: Optional[Batch], total_utterances: Optional[int] = None) -> Optional[Predictions]:
+        """``total_utterances``: size of THIS step's global batch (default: the constructor's), used by the padded gather."""
+        total = self._total if total_utterances is None else int(total_utterances)
         local = self._predict(local_batch) if local_batch is not None else None
         if not self._flat:
-            return self._padded(local)
+            return self._padded(local, total)
         if self._verify and not self._same_geometry(local):
-            # the flat gather cannot take this step: complete what is in flight (order on rank `dst`), then gather padded
-            self.drain()
-            return self._padded(local)
+            # the flat gather cannot take this step: complete what is in flight first (order on rank `dst`), then gather
+            # padded.  The in-flight gather is the PREVIOUS step's result and is what this call returns; this step's own
+            # result is complete as well and is parked for the next step() / drain().
+            had_pending = self._pending is not None
+            previous = self.drain()
+            result = self._padded(local, total)
+            if not had_pending:
+                return result
+            self._pending = _CompletedGather(result)
+            return previous
         handle = gather_flat_predictions(local, self._device, dst=self._dst, group=self._group, async_op=True)
         if not self._overlap:
             self.completed += 1
@@ -243,15 +276,13 @@ class DataParallelRunner:
         previous, self._pending = self._pending, handle
         if previous is None:
             return None
-        self.completed += 1
-        return previous.wait()
+        return self._finish(previous)
 
     def drain(self) -> Optional[Predictions]:
         if self._pending is None:
             return None
         pending, self._pending = self._pending, None
-        self.completed += 1
-        return pending.wait()
+        return self._finish(pending)
 
 
 def gather_decoded(local: Optional[Decoded], names: List[str], total_utterances: int, device: torch.device, dst: int = 0,
@@ -278,7 +309,11 @@ def gather_decoded(local: Optional[Decoded], names: List[str], total_utterances:
             raise ValueError("the local alignments do not cover this rank's block of utterances")
     if capacity is not None:
         k_max = int(capacity)
+        # an alignment has at most one entry per frame: a token tensor no wider than the capacity cannot overflow it (a
+        # static shape -- no read-back); a wider one is checked on `dst` after the gather
+        needs_check = local is not None and local.tokens.shape[2] > k_max
     else:
+        needs_check = False
         k_tensor = torch.zeros(1, dtype=torch.int32, device=device)
         if local is not None and local.counts.numel():
             k_tensor = local.counts.max().to(device=device, dtype=torch.int32).reshape(1)
@@ -297,6 +332,8 @@ def gather_decoded(local: Optional[Decoded], names: List[str], total_utterances:
         body[1, :, :n_local, :k_local] = local.timesteps[:, :, :k_local].to(device=device, dtype=torch.int32)
     gathered = [torch.empty_like(packed) for _ in range(world)] if rank == dst else None
     dist.gather(packed, gathered, dst=dst, group=group)
+    if needs_check and int(local.counts.max()) > k_max:
+        raise ValueError(f"an alignment of this rank holds more than capacity={k_max} tokens: it would be truncated")
     if rank != dst:
         return None
     result: Dict[str, List[List[CTCHypothesis]]] = {name: [] for name in names}
@@ -305,6 +342,8 @@ def gather_decoded(local: Optional[Decoded], names: List[str], total_utterances:
             continue
         block = gathered[r].cpu()
         counts = block[:head].view(n_out, n_max)
+        if counts.numel() and int(counts.max()) > k_max:  # the block is on the host already: no extra synchronisation
+            raise ValueError(f"rank {r} sent an alignment of {int(counts.max())} tokens, more than capacity={k_max}")
         scores = block[head: 2 * head].view(torch.float32).view(n_out, n_max)
         body = block[2 * head:].view(2, n_out, n_max, k_max).to(torch.int64)
         for o, name in enumerate(names):

@@ -51,6 +51,30 @@ def xlsr_300m_encoder() -> Dict[str, Any]:
     }
 
 
+def wav2vec2_base_encoder() -> Dict[str, Any]:
+    """``facebook/wav2vec2-base`` hyper-parameters: the group-norm feature extractor (GroupNorm over time behind conv layer 0,
+    bias-free convs), the post-LN encoder (``do_stable_layer_norm=False``), and a preprocessor with
+    ``return_attention_mask=False`` -- the reference then calls the model with ``attention_mask=None``
+    (acoustic_model.py:814,842-846).  ``facebook/wav2vec2-large`` is the same variant at 1024 / 24 / 16 / 4096."""
+    return {
+        "conv_dim": 512,
+        "conv_kernel": [10, 3, 3, 3, 3, 2, 2],
+        "conv_stride": [5, 2, 2, 2, 2, 2, 2],
+        "hidden": 768,
+        "layers": 12,
+        "heads": 12,
+        "ffn": 3072,
+        "pos_kernel": 128,
+        "pos_groups": 16,
+        "eps": 1e-5,
+        "do_normalize": True,
+        "feat_extract_norm": "group",
+        "conv_bias": False,
+        "stable_layer_norm": False,
+        "use_attention_mask": False,
+    }
+
+
 def tiny_encoder(layers: int = 2) -> Dict[str, Any]:
     """Reduced shape used by the committed golden vectors (same operator sequence as XLS-R)."""
     return {
@@ -183,8 +207,11 @@ def spec_from_reference_model(model) -> Dict[str, Any]:
     }
     if any(int(d) != spec["conv_dim"] for d in config.conv_dim):
         raise ValueError("feature-extractor layers of different widths are not supported")
-    if getattr(config, "feat_extract_norm", "layer") != "layer" or not getattr(config, "do_stable_layer_norm", True):
-        raise ValueError("only the layer-norm feature extractor / stable-layer-norm encoder variant (XLS-R) is supported")
+    # the variant: the reference builds whatever `model_id` names (acoustic_model.py:775-826)
+    spec["feat_extract_norm"] = str(getattr(config, "feat_extract_norm", "layer"))
+    spec["conv_bias"] = bool(getattr(config, "conv_bias", True))
+    spec["stable_layer_norm"] = bool(getattr(config, "do_stable_layer_norm", True))
+    spec["use_attention_mask"] = bool(getattr(acoustic, "_use_attention_mask", True))  # preprocessor return_attention_mask
     projection = model._projection
     dependencies = {name: [d.name for d in deps] for name, deps in projection._ordered_nodes}
     embedding_size = None
@@ -275,3 +302,6 @@ def validate(spec: Dict[str, Any]) -> None:
     evaluation_order(spec["classes"])
     if spec["hidden"] % spec["heads"] != 0:
         raise ValueError("hidden must be divisible by heads")
+    if spec.get("feat_extract_norm", "layer") not in ("layer", "group"):
+        # transformers' own message (Wav2Vec2FeatureEncoder.__init__)
+        raise ValueError(f"`config.feat_extract_norm` is {spec['feat_extract_norm']}, but has to be one of ['group', 'layer']")

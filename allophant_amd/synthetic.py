@@ -55,12 +55,16 @@ def make_state_dict(spec: Dict[str, Any], seed: int = 0, include_unused: bool = 
     if include_unused:
         put(AM + "masked_spec_embed", (D,), 1.0)
     c_in = 1
+    group = spec.get("feat_extract_norm", "layer") == "group"
     for i, k in enumerate(spec["conv_kernel"]):
         p = f"{AM}feature_extractor.conv_layers.{i}."
         put(p + "conv.weight", (C, c_in, k), math.sqrt(2.0 / (c_in * k)))
-        put(p + "conv.bias", (C,), 0.05)
-        put(p + "layer_norm.weight", (C,), 0.1, 1.0)
-        put(p + "layer_norm.bias", (C,), 0.1)
+        if spec.get("conv_bias", True):
+            put(p + "conv.bias", (C,), 0.05)
+        # "group": GroupNorm behind layer 0 only (same key names, transformers Wav2Vec2GroupNormConvLayer)
+        if not group or i == 0:
+            put(p + "layer_norm.weight", (C,), 0.1, 1.0)
+            put(p + "layer_norm.bias", (C,), 0.1)
         c_in = C
     p = AM + "feature_projection."
     put(p + "layer_norm.weight", (C,), 0.1, 1.0)

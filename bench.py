@@ -25,6 +25,7 @@ from __future__ import annotations
 import argparse
 import hashlib
 import json
+import math
 import os
 import socket
 import statistics
@@ -49,8 +50,18 @@ CONV0_PATTERN_STORE_GBS = 5660.0  # conv0's own store pattern without its arithm
 TRAFFIC_FILES = ("r03il_traffic.json", "r03_traffic.json", "r02_traffic.json")  # newest first; written by tools/collect_profiles.py
 
 
-def build_spec():
-    spec = S.multitask_spec(S.xlsr_300m_encoder(), allophone_layer=True)
+# BASELINE.json configs this file can time on one GPU (config 3 = config 2 under --gpus N; config 1 is CPU plumbing):
+# (utterances, seconds, phones of the synthetic inventory, hierarchical graph)
+CONFIG_PRESETS = {
+    2: (32, 10.0, 27, False),   # multitask, 'es'-sized inventory -- the configuration `metric` is quoted on (default)
+    4: (64, 5.0, 48, True),     # hierarchical: the phoneme head sees cat(OUTPUT, softmax(attribute logits)), ['es','it']-sized
+    5: (8, 60.0, 200, False),   # long-form stress: 200-phone inventory (its stated fp16 single-plane mode: --also f16)
+}
+
+
+def build_spec(hierarchical=False):
+    encoder = S.xlsr_300m_encoder()
+    spec = S.hierarchical_spec(encoder, allophone_layer=True) if hierarchical else S.multitask_spec(encoder, allophone_layer=True)
     spec["shared_phones"] = 80
     return spec
 
@@ -92,7 +103,9 @@ def work_model(spec, n, length, planes):
         products.append((M, shape[0], shape[1], spec["layers"]))
     attr_cols = sum(c["size"] + 1 for c in spec["classes"] if c["name"] != "phoneme")
     products.append((M, attr_cols, D, 1))
-    products.append((M, spec["embedding_size"], D, 1))
+    phoneme = next(c for c in spec["classes"] if c["name"] == "phoneme")
+    k_phoneme = synthetic.head_input_size(spec, phoneme)
+    products.append((M, spec["embedding_size"], (k_phoneme + 31) // 32 * 32, 1))  # K padded to the 32-element row blocks
     pp = tile = 0
     pp_launches = 0
     pp_bytes = 0
@@ -148,13 +161,14 @@ def physical_cores():
 
 def cpu_baseline(spec, state, tfi, audio, lengths):
     """Times the CPU oracle (oracle/allophant_oracle.py: the restatement pinned against the reference) on the host cores
-    of this box on a bounded sample of the same workload (the first utterances of the benchmark batch; SURVEY.md section
-    8d).  The thread count is chosen by a sweep on a two-utterance slice (physical cores, a half, a quarter, and 8 -- the
-    survey's container figure was taken on 8 threads): fp32 GEMMs of 499-row utterances stop scaling long before a 2-socket
-    box runs out of cores, and oversubscribing them is slower than a few cores.  The slice only ranks the counts: after one
-    warm-up run the two best are timed on the whole sample and the better one once more (median of its two runs).  Reported
-    baseline, not the target.  Returns (record, oracle outputs of the sample, frame
-    lengths) -- the outputs double as the parity spot check of the timed path."""
+    of this box on the sample it is given -- by default the WHOLE benchmark batch.  The thread count
+    is chosen first: a sweep on a two-utterance slice (physical cores, a half, a quarter, and 8 -- the survey's container
+    figure was taken on 8 threads) ranks the counts -- fp32 GEMMs of 499-row utterances stop scaling long before a 2-socket
+    box runs out of cores, and oversubscribing them is slower than a few cores -- and the two best are timed on the first 8
+    utterances (more utterances = more parallel work, so the slice's winner is not always the sample's).  The winner then
+    runs the whole sample ONCE, timed: that run is `value` (the 8-utterance trial doubles as its warm-up).  Reported baseline,
+    not the target.  Returns (record, oracle outputs of the sample, frame lengths) -- the outputs double as the parity spot
+    check of the timed path."""
     from oracle import allophant_oracle as O
 
     cores, logical = physical_cores()
@@ -168,32 +182,29 @@ def cpu_baseline(spec, state, tfi, audio, lengths):
         t0 = time.perf_counter()
         _, flen = O.predict(probe_a, probe_l, state, spec, tfi, offsets, True)
         sweep[threads] = int(flen.sum()) / (time.perf_counter() - t0)
-    # the slice ranks the counts; the two best are then timed on the whole sample (more utterances = more parallel work,
-    # so the slice's winner is not always the sample's), and the better of the two is timed once more
     ranked = sorted(sweep, key=sweep.get, reverse=True)[:2]
-    torch.set_num_threads(ranked[0])
-    O.predict(audio, lengths, state, spec, tfi, offsets, True)  # warm-up of the sample's shapes
-    trial, out, flen = {}, None, None
+    n_trial = min(8, len(lengths))
+    trial_a, trial_l = audio[:n_trial].contiguous(), lengths[:n_trial].contiguous()
+    trial = {}
     for threads in ranked:
         torch.set_num_threads(threads)
         t0 = time.perf_counter()
-        out, flen = O.predict(audio, lengths, state, spec, tfi, offsets, True)
-        trial[threads] = time.perf_counter() - t0
-    best = min(trial, key=trial.get)
+        _, flen = O.predict(trial_a, trial_l, state, spec, tfi, offsets, True)
+        trial[threads] = int(flen.sum()) / (time.perf_counter() - t0)
+    best = max(trial, key=trial.get)
     torch.set_num_threads(best)
     t0 = time.perf_counter()
     out, flen = O.predict(audio, lengths, state, spec, tfi, offsets, True)
-    times = [trial[best], time.perf_counter() - t0]
+    seconds = time.perf_counter() - t0
     frames = int(flen.sum())
-    med = statistics.median(times)
-    record = {"value": frames / med, "unit": "frames/s", "cores": best, "kind": "port",
+    record = {"value": frames / seconds, "unit": "frames/s", "cores": best, "kind": "port",
               "physical_cores": cores, "logical_cpus": logical,
               "thread_sweep_frames_per_s": {str(k): round(v, 1) for k, v in sweep.items()},
-              "sample_trial_frames_per_s": {str(k): round(frames / v, 1) for k, v in trial.items()},
-              "sample": f"the first {len(lengths)} x {audio.shape[1] / 16000:.0f} s utterances of the benchmark batch, fp32 torch CPU "
-                        f"oracle on {best} threads (a sweep over {candidates} on a 2-utterance slice ranks the counts, the two best "
-                        f"are timed on the sample; {cores} physical cores, {logical} logical CPUs), one warm-up run of the same "
-                        f"sample + median of {len(times)} timed runs ({med:.2f} s; all: " + ", ".join(f"{t:.2f}" for t in times) + " s)"}
+              "trial_frames_per_s": {str(k): round(v, 1) for k, v in trial.items()},
+              "sample": f"{len(lengths)} x {audio.shape[1] / 16000:.0f} s utterances of the benchmark batch, one timed run of "
+                        f"{seconds:.2f} s, fp32 torch CPU oracle on {best} threads (a sweep over {candidates} on a "
+                        f"2-utterance slice ranks the counts, the two best are timed on {n_trial} utterances, which is also the "
+                        f"warm-up; {cores} physical cores, {logical} logical CPUs)"}
     return record, out, flen
 
 
@@ -273,19 +284,33 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "bf16x3", "f16", "bf16"])
-    ap.add_argument("--utterances", type=int, default=32, help="utterances of the (global) batch")
-    ap.add_argument("--seconds", type=float, default=10.0)
-    ap.add_argument("--phones", type=int, default=27)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIG_PRESETS),
+                    help="BASELINE.json config to time on one GPU: 2 (default, the configuration `metric` is quoted on; config 3 "
+                         "under --gpus N), 4 (hierarchical, 64 x 5 s) or 5 (8 x 60 s, 200 phones)")
+    ap.add_argument("--utterances", type=int, default=None, help="utterances of the (global) batch (default: the config's)")
+    ap.add_argument("--seconds", type=float, default=None)
+    ap.add_argument("--phones", type=int, default=None)
     ap.add_argument("--also", default="bf16", choices=["", "f16x3", "bf16x3", "f16", "bf16"],
                     help="second precision mode reported under throughput_mode (N=1 only; empty string to skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=8, help="utterances of the batch the CPU baseline (and spot check) runs on")
+    ap.add_argument("--cpu-sample", type=int, default=0,
+                    help="utterances of the batch the CPU baseline (and the parity spot check) runs on; 0 = the whole batch "
+                         "(config 2: 32 x 10 s, ~25 s per oracle run on the box)")
     ap.add_argument("--no-spot-check", action="store_true", help="skip the oracle spot check of the timed path")
     ap.add_argument("--decoded-gather", action="store_true",
                     help="N > 1: also time the step that gathers greedy CTC alignments of the phoneme output instead of log-probs")
     ap.add_argument("--no-ragged", action="store_true", help="N = 1: skip the informational ragged-batch leg")
     ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the weak-scaling leg (32 x 10 s per GPU)")
     args = ap.parse_args()
+    preset = CONFIG_PRESETS[args.config]
+    if args.utterances is None:
+        args.utterances = preset[0]
+    if args.seconds is None:
+        args.seconds = preset[1]
+    if args.phones is None:
+        args.phones = preset[2]
+    if args.config != 2 and args.gpus > 1:
+        raise SystemExit("--gpus N > 1 times BASELINE config 3 (config 2 sharded); --config 4 / 5 are single-GPU lines")
 
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("AMX_BENCH_FORCE_LAUNCH") == "1"):
         # nothing above touched the GPU: this process only starts the ranks and relays rank 0's line
@@ -315,7 +340,7 @@ def main():
     from allophant_amd import parallel
     from allophant_amd.estimator import Batch, Estimator
 
-    spec = build_spec()
+    spec = build_spec(hierarchical=preset[3])
     state = synthetic.make_state_dict(spec, seed=0)
     tfi = synthetic.make_inventory(spec, args.phones, seed=0)
     length = int(args.seconds * 16000)
@@ -476,9 +501,12 @@ def main():
     result = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        config_name = "BASELINE config 2" if world == 1 else f"BASELINE config 3 (config 2 sharded {n_local} utterances per GPU x {world}, RCCL gather of log-probs to rank 0)"
+        config_name = f"BASELINE config {args.config}" if world == 1 else f"BASELINE config 3 (config 2 sharded {n_local} utterances per GPU x {world}, RCCL gather of log-probs to rank 0)"
+        graph_name = ("hierarchical checkpoint schema (36 attribute heads; the composed phoneme head reads cat(OUTPUT, softmax of every "
+                      "attribute head)" if preset[3] else "multitask checkpoint schema (36 attribute heads + composed phoneme head")
         result = {
-            "metric": "encoder frames/sec (whole node), 10s x 32 utterances @16kHz",
+            "metric": "encoder frames/sec (whole node), 10s x 32 utterances @16kHz" if args.config == 2 else
+                      f"encoder frames/sec (whole node), {args.seconds:g}s x {n_global} utterances @16kHz (BASELINE config {args.config})",
             "value": frames_global * args.steps / elapsed,
             "unit": "frames/s",
             "n_gpus": world,
@@ -491,9 +519,9 @@ def main():
             "dtype": args.precision,
             "data": "synthetic",
             "config": {
-                "workload": f"{config_name}: multitask checkpoint schema (36 attribute heads + composed phoneme head, allophone "
+                "workload": f"{config_name}: {graph_name}, allophone "
                             f"pass-through), global batch {n_global} x {args.seconds:.0f} s synthetic 16 kHz utterances, "
-                            f"{args.phones}-phone synthetic inventory ('es'-sized), procedural weights seed 0",
+                            f"{args.phones}-phone synthetic inventory, procedural weights seed 0",
                 "global_batch": n_global,
                 "utterances_per_gpu": n_local,
                 "frames_per_step": frames_global,
@@ -599,7 +627,9 @@ def main():
         # against the CPU oracle on those utterances (each result is independent of the batch it sits in: SURVEY.md Appendix
         # A), log-probs on valid frames.  Without the baseline leg the check runs the oracle on one utterance alone.
         oracle_out = oracle_len = None
-        n_check = max(1, min(args.cpu_sample, n_global)) if world == 1 else 1
+        # default: the whole batch (configs 2 / 4: ~25 s per oracle run); config 5's 60 s utterances: the first two
+        sample = (n_global if args.seconds <= 10.0 else min(2, n_global)) if args.cpu_sample <= 0 else min(args.cpu_sample, n_global)
+        n_check = sample if world == 1 else 1
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"], oracle_out, oracle_len = cpu_baseline(spec, state, tfi, audio[:n_check].contiguous(),
                                                                           lengths[:n_check].contiguous())
@@ -615,25 +645,39 @@ def main():
                                                        synthetic.category_offsets(spec), True)
                 est = Estimator(spec, state, device, args.precision)
                 pred = est.predict(local, tfi, True)  # rank 0's shard starts at utterance 0 of the global batch
+                range_error = None
+                try:
+                    est.check_finite()  # AMX_ERANGE: an activation left the fp16 planes (non-finite logits on a valid frame)
+                except FloatingPointError as exc:
+                    range_error = str(exc)
                 n_check = min(n_check, n_local)
-                worst, where = 0.0, None
+                worst, where, finite = 0.0, None, True
                 for name, expected in oracle_out.items():
                     got = pred.outputs[name][:, :n_check].cpu()
                     for i in range(n_check):
                         t_i = int(oracle_len[i])
                         err = (got[:t_i, i] - expected[:t_i, i]).abs().max().item()
-                        if err > worst:
+                        if not math.isfinite(err):  # a NaN compares false with everything: it must fail, not pass
+                            finite = False
+                            worst, where = float("inf"), (i, name)
+                        elif err > worst:
                             worst, where = err, (i, name)
                 est.close()
+                split = args.precision.endswith("x3")
                 result["parity_spot_check"] = {
-                    "max_abs": worst, "utterance": where[0] if where else None, "output": where[1] if where else None,
-                    "utterances_checked": n_check, "outputs_checked": len(oracle_out), "gate": 1e-3 if args.precision.endswith("x3") else None,
-                    "passed": bool(worst < 1e-3) if args.precision.endswith("x3") else None,
+                    "max_abs": worst if finite else None, "finite": finite, "range_check": range_error or "ok",
+                    "utterance": where[0] if where else None, "output": where[1] if where else None,
+                    "utterances_checked": n_check, "outputs_checked": len(oracle_out), "gate": 1e-3 if split else None,
+                    # the single-plane modes have no gate, but non-finite outputs fail in every mode
+                    "passed": bool(finite and range_error is None and (worst < 1e-3 or not split)),
                     "against": "CPU oracle (oracle/allophant_oracle.py) on the same utterances, log-probabilities of valid frames; "
                                "run after the timed region on the same handle configuration and batch",
                 }
             except Exception as exc:
-                result["parity_spot_check"] = {"error": repr(exc)}
+                result["parity_spot_check"] = {"error": repr(exc), "passed": False}
+            result["ok"] = bool(result["parity_spot_check"].get("passed"))
+        else:
+            result["ok"] = None  # not checked
     if use_dist:
         dist.barrier()  # the other ranks stay until rank 0 has finished its spot check: every rank leaves the group together
     sys.stdout.flush()
@@ -644,6 +688,10 @@ def main():
     if use_dist:
         os.dup2(2, 1)  # teardown chatter, if any, stays off stdout too
         dist.destroy_process_group()
+    if rank == 0 and result.get("ok") is False:
+        # the line above is still printed (it says what failed); the exit status says that the number must not be used
+        print("bench.py: the parity spot check of the timed path FAILED (see parity_spot_check)", file=sys.stderr)
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

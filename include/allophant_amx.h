@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define AMX_ABI_VERSION 3
+#define AMX_ABI_VERSION 4
 
 #define AMX_MAX_CONV 8
 #define AMX_MAX_DEPS 64
@@ -39,11 +39,16 @@ extern "C" {
 /* arithmetic modes of the GEMM-shaped products (activations between kernels are 16-bit planes, residual stream,
  * LayerNorm, softmax and all accumulation are fp32):
  *   BF16 / F16      one 16-bit plane per operand
- *   BF16X3 / F16X3  hi/lo split planes, 3 MFMAs per product: fp32-grade results (the 1e-3 logit parity gate) */
+ *   BF16X3 / F16X3  hi/lo split planes, 3 MFMAs per product.  F16X3 is the parity mode (max-abs log-prob error 4-9e-5
+ *                   against the reference at XLS-R shape, all greedy alignments equal); BF16X3 has the range of fp32 but
+ *                   16 mantissa bits per product: 4e-4, inside the 1e-3 gate, one of 76 golden alignments differs */
 #define AMX_PREC_BF16 0
 #define AMX_PREC_F16 1
 #define AMX_PREC_BF16X3 2
 #define AMX_PREC_F16X3 3
+
+#define AMX_NORM_LAYER 0
+#define AMX_NORM_GROUP 1
 
 /* amx_forward flags */
 #define AMX_FLAG_HOST_IO 1u      /* audio / out are host pointers; the library stages them over PCIe */
@@ -52,6 +57,8 @@ extern "C" {
 #define AMX_FLAG_TIMING 8u       /* bracket every kernel launch with HIP events on the launch stream (amx_timing_fetch) */
 #define AMX_FLAG_PADDED 16u      /* L may exceed max(lengths): the call is one slice of a larger batch padded to L (the
                                     reference itself requires L == max(lengths), utils.py:62-63) */
+#define AMX_FLAG_CONTINUE 64u    /* the call continues the range-check count of the previous call instead of restarting it: slices
+                                  * 2.. of one over-long batch (amx_check_finite then reports on the whole batch) */
 #define AMX_FLAG_NO_PACK 32u     /* keep the padded [N, T] row layout through the encoder layers even for a ragged batch (the
                                   * default runs them on the valid frames only; results on valid frames are identical) */
 
@@ -92,6 +99,17 @@ typedef struct amx_config {
     int32_t embedding_size;              /* EmbeddingCompositionConfig.embedding_size, 0 = no composition layer */
     int32_t allophone_layer;             /* 1: predict mode also publishes "phone" (acoustic_model.py:161-167) */
     int32_t precision;                   /* AMX_PREC_* */
+    /* ABI 4: the wav2vec 2.0 variant (`Wav2Vec2Config` fields the reference passes through untouched: it builds whatever
+     * `model_id` names, acoustic_model.py:775-826).  XLS-R / every released Allophant checkpoint: 0, 1, 1, 1. */
+    int32_t feat_extract_norm;           /* AMX_NORM_LAYER: LayerNorm over channels behind every conv layer; AMX_NORM_GROUP:
+                                            GroupNorm(conv_dim groups) over time behind conv layer 0 only (wav2vec2-base/-large) */
+    int32_t conv_bias;                   /* config.conv_bias: the conv layers carry a bias */
+    int32_t stable_layer_norm;           /* config.do_stable_layer_norm: 1 = pre-LN layers + final LayerNorm
+                                            (Wav2Vec2EncoderStableLayerNorm), 0 = LayerNorm behind the positional convolution and
+                                            post-LN layers (Wav2Vec2Encoder) */
+    int32_t use_attention_mask;          /* preprocessor return_attention_mask (acoustic_model.py:814,842-846): 0 = the model is
+                                            called with attention_mask=None -- padded frames are neither zeroed nor masked as
+                                            keys; `Predictions.lengths` are the downsampled lengths either way */
 } amx_config;
 
 /* One classifier of the hierarchical projection (`ProjectionEntryConfig` / `AttributeNode`,
@@ -171,8 +189,8 @@ int amx_synchronize(amx_handle h, void* stream);
  * ACTIVATION (or a non-finite input sample) can leave that range, and it then reaches the logits as an infinity or a NaN.
  * Waits for `stream`, stores the number of valid frames with non-finite logits in *frames (may be NULL) and returns AMX_OK
  * when there are none, AMX_ERANGE otherwise (amx_last_error names the remedy: precision bf16x3 has the range of fp32).
- * The count covers the last amx_forward; calls with AMX_FLAG_PADDED (slices of one batch) add to it instead of restarting
- * it, and a check resets it. */
+ * The count covers the last amx_forward; calls with AMX_FLAG_CONTINUE (the later slices of one batch) add to it instead of
+ * restarting it, and a check resets it (in stream order). */
 int amx_check_finite(amx_handle h, void* stream, int64_t* frames);
 
 /* Replaces `GreedyCTCDecoder.__call__` (predictions.py:194-207), applied to every output of a prediction as the

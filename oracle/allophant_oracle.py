@@ -11,10 +11,14 @@ PARITY PIN: this restatement is pinned against the *real* reference (imported in
 holds no tests or golden vectors for this path, so outputs of the reference itself are the pin.
 
 The heavy arithmetic of the path lives in a third-party dependency that is not vendored in /root/reference:
-``transformers==4.41.2`` (``pyproject.toml:23``), class ``Wav2Vec2Model`` with ``do_stable_layer_norm=True`` and
-``feat_extract_norm="layer"`` (XLS-R); the build container has transformers 5.15.0, which is what the goldens were
-generated with.  Its published algorithm is restated in ``wav2vec2_hidden_states`` below; the reference's own call
-site is ``allophant/network/acoustic_model.py:837-853``.
+``transformers==4.41.2`` (``pyproject.toml:23``), class ``Wav2Vec2Model``; the build container has transformers 5.15.0,
+which is what the goldens were generated with.  Its published algorithm is restated in ``wav2vec2_hidden_states`` below
+for both variants the reference can be pointed at (it builds whatever ``model_id`` names, acoustic_model.py:775-826):
+``feat_extract_norm="layer"`` + ``do_stable_layer_norm=True`` (XLS-R, every released Allophant checkpoint) and
+``feat_extract_norm="group"`` + ``do_stable_layer_norm=False`` (wav2vec2-base / -large: GroupNorm over time behind conv
+layer 0 only, bias-free convs, post-LN encoder layers; their preprocessor has ``return_attention_mask=False``, so the
+reference calls the model with ``attention_mask=None``, acoustic_model.py:814,842-846).  The reference's own call site is
+``allophant/network/acoustic_model.py:837-853``.
 
 Reference lines followed (all relative to /root/reference):
   mask_sequence                     allophant/utils.py:45-76
@@ -102,7 +106,7 @@ def topological_order(classes: Sequence[Dict[str, Any]]) -> List[int]:
 
 
 # ----------------------------------------------------------------------------------------------------------------
-# wav2vec 2.0 (stable-layer-norm / layer-norm feature extractor variant), restated
+# wav2vec 2.0 (both variants: layer-norm extractor + pre-LN encoder, group-norm extractor + post-LN encoder), restated
 # ----------------------------------------------------------------------------------------------------------------
 def _pos_conv_weight(state: Dict[str, Tensor]) -> Tensor:
     base = _AM + "encoder.pos_conv_embed.conv."
@@ -118,14 +122,23 @@ def _pos_conv_weight(state: Dict[str, Tensor]) -> Tensor:
 
 
 def feature_encoder(x: Tensor, state: Dict[str, Tensor], spec: Dict[str, Any]) -> Tensor:
-    """7 x [Conv1d -> LayerNorm over channels -> exact GELU]; returns [N, T, C] (channels last)."""
+    """``feat_extract_norm="layer"``: 7 x [Conv1d -> LayerNorm over channels -> exact GELU] (Wav2Vec2LayerNormConvLayer);
+    ``"group"``: [Conv1d -> GroupNorm(C groups of one channel: statistics over TIME, of the padded batch tensor) -> GELU]
+    for layer 0 (Wav2Vec2GroupNormConvLayer), then 6 x [Conv1d -> GELU] (Wav2Vec2NoLayerNormConvLayer).  ``conv_bias``
+    False: bias-free convolutions.  Returns [N, T, C] (channels last)."""
+    group = spec.get("feat_extract_norm", "layer") == "group"
     h = x.unsqueeze(1)
     for i, (k, s) in enumerate(zip(spec["conv_kernel"], spec["conv_stride"])):
         p = f"{_AM}feature_extractor.conv_layers.{i}."
-        h = F.conv1d(h, state[p + "conv.weight"], state[p + "conv.bias"], stride=s)
-        h = h.transpose(-2, -1)
-        h = F.layer_norm(h, (h.shape[-1],), state[p + "layer_norm.weight"], state[p + "layer_norm.bias"], 1e-5)
-        h = h.transpose(-2, -1)
+        bias = state[p + "conv.bias"] if spec.get("conv_bias", True) else None
+        h = F.conv1d(h, state[p + "conv.weight"], bias, stride=s)
+        if group:
+            if i == 0:
+                h = F.group_norm(h, h.shape[1], state[p + "layer_norm.weight"], state[p + "layer_norm.bias"], 1e-5)
+        else:
+            h = h.transpose(-2, -1)
+            h = F.layer_norm(h, (h.shape[-1],), state[p + "layer_norm.weight"], state[p + "layer_norm.bias"], 1e-5)
+            h = h.transpose(-2, -1)
         h = F.gelu(h)
     return h.transpose(1, 2)
 
@@ -149,10 +162,16 @@ def wav2vec2_hidden_states(
     T = feats.shape[1]
     frame_mask = torch.arange(T).unsqueeze(0) < frame_lengths.unsqueeze(1)  # == _get_feature_vector_attention_mask
 
+    # `use_attention_mask` False (preprocessor return_attention_mask=False): attention_mask=None -- no frame is zeroed and
+    # every key is attended to (acoustic_model.py:842-846); the returned frame lengths are the downsampled ones either way
+    masked = bool(spec.get("use_attention_mask", True))
+    stable = bool(spec.get("stable_layer_norm", True))
+
     p = _AM + "feature_projection."
     h = F.layer_norm(feats, (feats.shape[-1],), state[p + "layer_norm.weight"], state[p + "layer_norm.bias"], eps)
     h = F.linear(h, state[p + "projection.weight"], state[p + "projection.bias"])
-    h = h * frame_mask.unsqueeze(-1)  # hidden_states[~mask] = 0
+    if masked:
+        h = h * frame_mask.unsqueeze(-1)  # hidden_states[~mask] = 0
 
     k = spec["pos_kernel"]
     pos = F.conv1d(
@@ -169,12 +188,17 @@ def wav2vec2_hidden_states(
     N = h.shape[0]
     # additive key-padding bias (finfo.min on padded keys; padded *queries* are still computed)
     bias = torch.zeros(N, 1, 1, T)
-    bias.masked_fill_(~frame_mask[:, None, None, :], torch.finfo(torch.float32).min)
+    if masked:
+        bias.masked_fill_(~frame_mask[:, None, None, :], torch.finfo(torch.float32).min)
+    if not stable:
+        # Wav2Vec2Encoder (post-LN): the encoder LayerNorm sits behind the positional convolution
+        h = F.layer_norm(h, (D,), state[_AM + "encoder.layer_norm.weight"], state[_AM + "encoder.layer_norm.bias"], eps)
     hidden_states: List[Tensor] = []
     for i in range(spec["layers"]):
         hidden_states.append(h)
         p = f"{_AM}encoder.layers.{i}."
-        a = F.layer_norm(h, (D,), state[p + "layer_norm.weight"], state[p + "layer_norm.bias"], eps)
+        # pre-LN (Wav2Vec2EncoderLayerStableLayerNorm): attention on LayerNorm(h); post-LN (Wav2Vec2EncoderLayer): on h
+        a = F.layer_norm(h, (D,), state[p + "layer_norm.weight"], state[p + "layer_norm.bias"], eps) if stable else h
         q = F.linear(a, state[p + "attention.q_proj.weight"], state[p + "attention.q_proj.bias"])
         kk = F.linear(a, state[p + "attention.k_proj.weight"], state[p + "attention.k_proj.bias"])
         v = F.linear(a, state[p + "attention.v_proj.weight"], state[p + "attention.v_proj.bias"])
@@ -185,11 +209,20 @@ def wav2vec2_hidden_states(
         attn = torch.matmul(torch.softmax(scores, dim=-1), v)
         attn = attn.transpose(1, 2).reshape(N, T, D)
         h = h + F.linear(attn, state[p + "attention.out_proj.weight"], state[p + "attention.out_proj.bias"])
-        f = F.layer_norm(h, (D,), state[p + "final_layer_norm.weight"], state[p + "final_layer_norm.bias"], eps)
-        f = F.gelu(F.linear(f, state[p + "feed_forward.intermediate_dense.weight"],
-                            state[p + "feed_forward.intermediate_dense.bias"]))
-        h = h + F.linear(f, state[p + "feed_forward.output_dense.weight"], state[p + "feed_forward.output_dense.bias"])
-    h = F.layer_norm(h, (D,), state[_AM + "encoder.layer_norm.weight"], state[_AM + "encoder.layer_norm.bias"], eps)
+
+        def ffn(x):
+            x = F.gelu(F.linear(x, state[p + "feed_forward.intermediate_dense.weight"],
+                                state[p + "feed_forward.intermediate_dense.bias"]))
+            return F.linear(x, state[p + "feed_forward.output_dense.weight"], state[p + "feed_forward.output_dense.bias"])
+
+        if stable:
+            h = h + ffn(F.layer_norm(h, (D,), state[p + "final_layer_norm.weight"], state[p + "final_layer_norm.bias"], eps))
+        else:
+            h = F.layer_norm(h, (D,), state[p + "layer_norm.weight"], state[p + "layer_norm.bias"], eps)
+            h = h + ffn(h)
+            h = F.layer_norm(h, (D,), state[p + "final_layer_norm.weight"], state[p + "final_layer_norm.bias"], eps)
+    if stable:
+        h = F.layer_norm(h, (D,), state[_AM + "encoder.layer_norm.weight"], state[_AM + "encoder.layer_norm.bias"], eps)
     hidden_states.append(h)
     return hidden_states, frame_lengths, inter
 

@@ -82,7 +82,9 @@ def run_case(name, spec, n, length, ragged, inventory_phones, seed, store_weight
     # hidden states straight from the HF module for an intermediate pin
     with torch.inference_mode():
         mask = O.mask_sequence(lengths)
-        hf = model._acoustic_model._model(O.zero_mean_unit_var_norm(audio, lengths, mask), mask.long(),
+        # the call of acoustic_model.py:839-847: attention_mask=None when the preprocessor has return_attention_mask=False
+        hf = model._acoustic_model._model(O.zero_mean_unit_var_norm(audio, lengths, mask),
+                                          mask.long() if spec.get("use_attention_mask", True) else None,
                                           output_hidden_states=True)
     fm = (torch.arange(flen.max()).unsqueeze(0) < flen.unsqueeze(1)).unsqueeze(-1)
     herr = max(((a - b).abs() * fm).max().item() for a, b in zip(hf.hidden_states, inter["hidden_states"]))
@@ -219,7 +221,7 @@ def integer_goldens():
 
 def main():
     torch.set_num_threads(8)
-    which = set(sys.argv[1:]) or {"g1", "g2", "g2b", "g3", "g4", "g5", "g8"}
+    which = set(sys.argv[1:]) or {"g1", "g2", "g2b", "g3", "g4", "g5", "g8", "g11", "g11b", "g12"}
     tiny = S.tiny_encoder(2)
     if "g4" in which:
         integer_goldens()
@@ -266,6 +268,38 @@ def main():
             {"name": "phoneme", "size": 9, "dependencies": ["OUTPUT", "long", "nasal"]},
         ]
         run_case("g8_tiny_time_layer", spec, n=3, length=5200, ragged=True, inventory_phones=8, seed=8, store_weights=False)
+    if "g11" in which:
+        # G11: the group-norm / post-LN wav2vec 2.0 variant (wav2vec2-base / -large: feat_extract_norm="group", conv_bias=False,
+        # do_stable_layer_norm=False) with a preprocessor that has return_attention_mask=False, i.e. the reference calls the
+        # model with attention_mask=None (acoustic_model.py:814,842-846); tiny shape, ragged batch, hierarchical graph with an
+        # OUTPUT_i dependency so that intermediate hidden states of the post-LN stack are pinned too
+        enc = S.tiny_encoder(3)
+        enc.update(feat_extract_norm="group", conv_bias=False, stable_layer_norm=False, use_attention_mask=False)
+        spec = S.multitask_spec(enc, ["syllabic", "long"], embedding_size=16, train_phonemes=9, n_features=5)
+        spec["classes"] = [
+            {"name": "syllabic", "size": 3, "dependencies": ["OUTPUT_1"]},
+            {"name": "long", "size": 2, "dependencies": ["OUTPUT"]},
+            {"name": "phoneme", "size": 9, "dependencies": ["OUTPUT", "syllabic", "long"]},
+        ]
+        run_case("g11_tiny_groupnorm_postln", spec, n=3, length=5600, ragged=True, inventory_phones=7, seed=11,
+                 store_weights=False)
+    if "g11b" in which:
+        # G11b: the same variant WITH the attention mask (a group-norm checkpoint whose preprocessor returns one), plus a conv
+        # bias: frames beyond an utterance are zeroed / masked as keys, the GroupNorm still runs over the padded length
+        enc = S.tiny_encoder(2)
+        enc.update(feat_extract_norm="group", conv_bias=True, stable_layer_norm=False, use_attention_mask=True)
+        spec = S.multitask_spec(enc, ["syllabic", "long", "nasal"], embedding_size=16, train_phonemes=9, n_features=5,
+                                allophone_layer=True)
+        spec["shared_phones"] = 11
+        run_case("g11b_tiny_groupnorm_masked", spec, n=3, length=6000, ragged=True, inventory_phones=7, seed=12,
+                 store_weights=False)
+    if "g12" in which:
+        # G12: full wav2vec2-base shape (768 / 12 layers / 12 heads / 3072) of the group-norm / post-LN variant, procedural
+        # weights, 2 x 3 s ragged, attention_mask=None; sub-sampled tensors only
+        spec = S.multitask_spec(S.wav2vec2_base_encoder(), allophone_layer=True)
+        spec["shared_phones"] = 80
+        run_case("g12_w2v2base_multitask", spec, n=2, length=48000, ragged=True, inventory_phones=27, seed=0,
+                 store_weights=False, subsample=[0, 1, 6, 12], store_audio=False)
     if "g3" in which:
         # G3: full XLS-R shape, procedural weights (seed 0), 2 x 3 s ragged; sub-sampled tensors only
         spec = S.multitask_spec(S.xlsr_300m_encoder(), allophone_layer=True)

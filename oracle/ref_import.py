@@ -173,13 +173,13 @@ def write_hf_model_dir(spec: Dict[str, Any], directory: str) -> str:
         "intermediate_size": spec["ffn"],
         "hidden_act": "gelu",
         "feat_extract_activation": "gelu",
-        "feat_extract_norm": "layer",
-        "conv_bias": True,
+        "feat_extract_norm": spec.get("feat_extract_norm", "layer"),
+        "conv_bias": bool(spec.get("conv_bias", True)),
         "conv_dim": [spec["conv_dim"]] * n,
         "conv_kernel": list(spec["conv_kernel"]),
         "conv_stride": list(spec["conv_stride"]),
         "num_feat_extract_layers": n,
-        "do_stable_layer_norm": True,
+        "do_stable_layer_norm": bool(spec.get("stable_layer_norm", True)),
         "num_conv_pos_embeddings": spec["pos_kernel"],
         "num_conv_pos_embedding_groups": spec["pos_groups"],
         "layer_norm_eps": spec["eps"],
@@ -190,7 +190,8 @@ def write_hf_model_dir(spec: Dict[str, Any], directory: str) -> str:
     }
     preprocessor = {
         "do_normalize": True, "feature_extractor_type": "Wav2Vec2FeatureExtractor", "feature_size": 1,
-        "padding_side": "right", "padding_value": 0, "return_attention_mask": True, "sampling_rate": 16000,
+        "padding_side": "right", "padding_value": 0, "return_attention_mask": bool(spec.get("use_attention_mask", True)),
+        "sampling_rate": 16000,
     }
     os.makedirs(directory, exist_ok=True)
     with open(os.path.join(directory, "config.json"), "w") as f:

@@ -329,3 +329,92 @@ def test_runner_with_empty_and_uneven_shards(tmp_path):
             valid = (torch.arange(ref[name].shape[0]).unsqueeze(1) < ref_len.unsqueeze(0)).unsqueeze(-1)
             assert g["outputs"][name].shape == ref[name].shape, (step, name)
             assert ((g["outputs"][name] - ref[name]).abs() * valid).max().item() < 1e-4, (step, name)
+
+
+# ---- one runner across steps [equal, equal, ragged, smaller last batch, equal] (round-3 advisor finding) ----
+_MIXED_STEPS = [(4, False), (4, False), (3, True), (2, False), (4, False)]
+
+
+def _mixed_runner_worker(rank, world, port, result_path):
+    from oracle import allophant_oracle as O
+    from allophant_amd.parallel import DataParallelRunner
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    spec, state, _, _, tfi = _setup()
+    offsets = synthetic.category_offsets(spec)
+
+    def predict(batch):
+        out, flen = O.predict(batch.audio_features, batch.lengths, state, spec, tfi, offsets)
+        return _flat_predictions(out, flen)
+
+    # total_utterances of the constructor is the usual batch size; the ragged and the smaller batch pass their own
+    runner = DataParallelRunner(predict, torch.device("cpu"), dst=0, total_utterances=4,
+                                outputs=[("syllabic", 4), ("long", 4), ("phoneme", 7)], aliases={"phone": "phoneme"})
+    delivered = []
+    for step, (total, ragged) in enumerate(_MIXED_STEPS):
+        audio, lengths = synthetic.make_audio(total, 2400, seed=90 + step, ragged=ragged)
+        shard = shard_batch(Batch(audio, lengths, torch.zeros(total, dtype=torch.long)), rank, world)
+        delivered.append(runner.step(shard, total_utterances=total))
+    delivered.append(runner.drain())
+    assert runner.drain() is None  # nothing is handed out twice
+    assert delivered[0] is None    # step 0's gather is still in flight when step 0 returns
+    if rank == 0:
+        results = [d for d in delivered if d is not None]
+        assert runner.completed == len(_MIXED_STEPS) == len(results), (runner.completed, len(results))
+        torch.save([{"outputs": dict(r.outputs), "lengths": r.lengths.cpu()} for r in results], result_path)
+    else:
+        assert all(d is None for d in delivered)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_runner_delivers_every_step_once_and_in_order(tmp_path):
+    """An overlapped runner that has to fall back to the padded gather while the previous step's flat gather is in flight
+    must not drop that step: across [equal, equal, ragged, smaller, equal] every step's global predictions come out exactly
+    once, in step order."""
+    from oracle import allophant_oracle as O
+
+    result_path = str(tmp_path / "mixed.pt")
+    mp.spawn(_mixed_runner_worker, args=(2, _free_port(), result_path), nprocs=2, join=True)
+    got = torch.load(result_path)
+    spec, state, _, _, tfi = _setup()
+    assert len(got) == len(_MIXED_STEPS)
+    for step, (total, ragged) in enumerate(_MIXED_STEPS):
+        audio, lengths = synthetic.make_audio(total, 2400, seed=90 + step, ragged=ragged)
+        ref, ref_len = O.predict(audio, lengths, state, spec, tfi, synthetic.category_offsets(spec))
+        g = got[step]
+        assert list(g["outputs"]) == list(ref), step
+        assert g["lengths"].tolist() == ref_len.tolist(), step
+        for name in ref:
+            valid = (torch.arange(ref[name].shape[0]).unsqueeze(1) < ref_len.unsqueeze(0)).unsqueeze(-1)
+            assert g["outputs"][name].shape == ref[name].shape, (step, name)
+            assert ((g["outputs"][name] - ref[name]).abs() * valid).max().item() < 1e-4, (step, name)
+
+
+def _overflow_worker(rank, world, port):
+    from allophant_amd.estimator import Decoded
+    from allophant_amd.parallel import gather_decoded
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    full = _global_decoded(4, seed=78)
+    full.counts[:, 3] = 20  # an alignment of 20 tokens on rank 1
+    lo, hi = shard_bounds(4, world)[rank]
+    local = Decoded(full.names, full.tokens[:, lo:hi], full.timesteps[:, lo:hi], full.counts[:, lo:hi], full.scores[:, lo:hi])
+    try:
+        gather_decoded(local, ["phoneme"], 4, torch.device("cpu"), dst=0, capacity=8)
+        raised = False
+    except ValueError:
+        raised = True
+    # rank 0 sees the over-long count in the gathered block, rank 1 in its own alignments
+    assert raised, rank
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_decoded_gather_refuses_alignments_beyond_the_capacity():
+    mp.spawn(_overflow_worker, args=(2, _free_port()), nprocs=2, join=True)

@@ -23,7 +23,7 @@ def test_library_loads_and_exports_every_declared_symbol():
 
 def test_struct_layout_matches_header():
     # sizes implied by include/allophant_amx.h (all members are 4-byte aligned scalars / arrays)
-    assert C.sizeof(lib.AmxConfig) == 4 * (3 + 8 + 8 + 6 + 1 + 5)
+    assert C.sizeof(lib.AmxConfig) == 4 * (3 + 8 + 8 + 6 + 1 + 5 + 4)  # + the four variant fields of ABI 4
     assert C.sizeof(lib.AmxClassDesc) == 48 + 4 * 3 + 4 * 64 + 4 * 2  # + time_heads, time_positional (ABI 2)
     assert C.sizeof(lib.AmxOutputDesc) == 48 + 4 + 4 + 8  # int32 + padding + int64
     assert C.sizeof(lib.AmxTensor) == 24
@@ -214,3 +214,29 @@ def test_bench_helpers_hash_gate_and_core_count(tmp_path, monkeypatch):
     assert data == {"hbm_bytes_per_launch": 3.0} and "new.json" in why and "feedfacefeedface" in why
     assert bench.load_traffic("bf16") == (None, None) or bench.load_traffic("bf16")[0] is None
     assert os.path.isdir(os.path.join(os.path.dirname(os.path.abspath(bench.__file__)), "allophant_amd", "csrc"))
+
+
+def test_checkpoint_model_id_selects_the_wav2vec2_variant():
+    """`nn.acoustic_model.model_id` decides the encoder the reference builds (acoustic_model.py:775-826): a checkpoint naming
+    wav2vec2-base restores as the group-norm / post-LN variant without the attention mask, XLS-R as before, an unknown id is
+    refused, and an explicit `amx_encoder` override carries the variant keys."""
+    base = S.baseline_spec(S.wav2vec2_base_encoder(), 40)
+    base["model_id"] = "facebook/wav2vec2-base"
+    restored = checkpoint.spec_from_checkpoint(checkpoint.make_checkpoint(base, {}, synthetic_encoder=False))
+    assert restored["feat_extract_norm"] == "group" and restored["conv_bias"] is False
+    assert restored["stable_layer_norm"] is False and restored["use_attention_mask"] is False
+    assert (restored["hidden"], restored["layers"], restored["heads"], restored["ffn"]) == (768, 12, 12, 3072)
+    xlsr = checkpoint.spec_from_checkpoint(checkpoint.make_checkpoint(S.baseline_spec(S.xlsr_300m_encoder(), 40), {}))
+    assert xlsr.get("feat_extract_norm", "layer") == "layer" and xlsr.get("stable_layer_norm", True)
+    unknown = S.baseline_spec(S.xlsr_300m_encoder(), 40)
+    unknown["model_id"] = "someone/some-model"
+    with pytest.raises(ValueError):
+        checkpoint.spec_from_checkpoint(checkpoint.make_checkpoint(unknown, {}))
+    enc = S.tiny_encoder(1)
+    enc.update(feat_extract_norm="group", conv_bias=False, stable_layer_norm=False, use_attention_mask=False)
+    tiny = checkpoint.spec_from_checkpoint(checkpoint.make_checkpoint(S.baseline_spec(enc, 7), {}, synthetic_encoder=True))
+    assert tiny["feat_extract_norm"] == "group" and tiny["use_attention_mask"] is False
+    cfg, _ = _spec_to_structs(tiny, "f16x3")
+    assert (cfg.feat_extract_norm, cfg.conv_bias, cfg.stable_layer_norm, cfg.use_attention_mask) == (lib.NORM_GROUP, 0, 0, 0)
+    cfg, _ = _spec_to_structs(S.baseline_spec(S.tiny_encoder(1), 7), "f16x3")
+    assert (cfg.feat_extract_norm, cfg.conv_bias, cfg.stable_layer_norm, cfg.use_attention_mask) == (lib.NORM_LAYER, 1, 1, 1)

@@ -15,7 +15,10 @@ from oracle import allophant_oracle as O
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TINY = ["g1_tiny_multitask", "g2_tiny_hierarchical", "g2b_tiny_hierarchical_blanks", "g5_tiny_baseline",
-        "g8_tiny_time_layer"]  # g8: time-layer (ProjectingMultiheadAttention) classifiers, with and without positions
+        "g8_tiny_time_layer",  # g8: time-layer (ProjectingMultiheadAttention) classifiers, with and without positions
+        # the group-norm / post-LN wav2vec 2.0 variant (wav2vec2-base / -large): g11 as the reference runs such a model
+        # (attention_mask=None), g11b with the attention mask and a conv bias
+        "g11_tiny_groupnorm_postln", "g11b_tiny_groupnorm_masked"]
 
 
 @pytest.mark.parametrize("name", TINY)
@@ -57,6 +60,23 @@ def test_oracle_matches_reference_xlsr_shape():
     for i in g.hidden_indices():
         assert max_abs_valid_bm(inter["hidden_states"][i][:, :, ::8], g.hidden(i), g.frame_lengths) < 1e-4, i
     assert torch.equal(out["phone"], out["phoneme"])
+
+
+def test_oracle_matches_reference_wav2vec2_base_shape():
+    """Full wav2vec2-base shape (768 / 12 / 12 / 3072) of the group-norm / post-LN variant, attention_mask=None, procedural
+    weights, 2 x 3 s ragged (sub-sampled golden tensors)."""
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    g = Golden("g12_w2v2base_multitask")
+    assert g.spec["feat_extract_norm"] == "group" and not g.spec["stable_layer_norm"] and not g.spec["use_attention_mask"]
+    out, flen, inter = O.predict(g.audio, g.lengths, g.state_dict(), g.spec, g.tfi, g.category_offsets, True,
+                                 keep_intermediates=True)
+    assert list(out.keys()) == g.output_names and len(g.output_names) == 38
+    assert torch.equal(flen, g.frame_lengths)
+    worst = max(max_abs_valid_tm(out[k], g.logprobs(k), g.frame_lengths) for k in g.output_names)
+    assert worst < 2e-4, worst
+    assert max_abs_valid_bm(inter["conv_out"][:, :, ::8], g.conv_out(), g.frame_lengths) < 1e-5
+    for i in g.hidden_indices():
+        assert max_abs_valid_bm(inter["hidden_states"][i][:, :, ::8], g.hidden(i), g.frame_lengths) < 1e-4, i
 
 
 def _g4():

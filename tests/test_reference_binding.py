@@ -33,6 +33,8 @@ def _comparable(spec):
     keys = ("conv_dim", "conv_kernel", "conv_stride", "hidden", "layers", "heads", "ffn", "pos_kernel", "pos_groups", "eps",
             "do_normalize", "dependency_blanks", "embedding_size", "allophone_layer", "composition_categories")
     out = {k: spec.get(k) for k in keys}
+    out["variant"] = (spec.get("feat_extract_norm", "layer"), bool(spec.get("conv_bias", True)),
+                      bool(spec.get("stable_layer_norm", True)), bool(spec.get("use_attention_mask", True)))
     out["classes"] = [{"name": c["name"], "dependencies": list(c["dependencies"]), "time_layer": c.get("time_layer")}
                       for c in spec["classes"]]
     out["embedding_size"] = out["embedding_size"] or None
@@ -75,3 +77,21 @@ def test_spec_from_a_live_reference_model_baseline():
     derived = S.spec_from_reference_model(model)
     assert _comparable(derived) == _comparable(spec)
     assert derived["classes"][0]["size"] == 14 and S.training_inventory_of_reference_model(model) is None
+
+
+def test_spec_from_a_live_reference_model_groupnorm_postln():
+    """The reference builds whatever ``model_id`` names (acoustic_model.py:775-826): a group-norm / post-LN wav2vec 2.0 whose
+    preprocessor has return_attention_mask=False comes out as that variant, and its state_dict has no conv bias and a norm
+    behind conv layer 0 only."""
+    enc = S.tiny_encoder(2)
+    enc.update(feat_extract_norm="group", conv_bias=False, stable_layer_norm=False, use_attention_mask=False)
+    spec = S.baseline_spec(enc, 12)
+    model, _ = _reference_model(spec, 12)
+    derived = S.spec_from_reference_model(model)
+    assert _comparable(derived) == _comparable(spec)
+    assert derived["feat_extract_norm"] == "group" and derived["use_attention_mask"] is False
+    state = synthetic.make_state_dict(spec, seed=0)
+    reference_keys = set(model.state_dict())
+    assert set(state) <= reference_keys
+    extractor = {k for k in reference_keys if ".feature_extractor." in k}
+    assert extractor == {k for k in state if ".feature_extractor." in k}  # no bias, one norm: exactly the generated keys
