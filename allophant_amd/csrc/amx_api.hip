@@ -74,6 +74,8 @@ struct amx_handle_s {
     float* conv_g[AMX_MAX_CONV] = {};
     float* conv_be[AMX_MAX_CONV] = {};
     void* conv_w[AMX_MAX_CONV] = {};
+    void* conv_w_tm[AMX_MAX_CONV] = {};  // the same weights in tap-minor K order (GemmParams.a_taps), for the row-complete kernel
+    int conv_tm_slice = 0;               // channels per slice of that order (0: no such copy)
     // Range of the 16-bit planes: every weight tensor is packed times a power of two that puts its largest element into
     // [4096, 8192) (exact, so results do not change) and the product's epilogue multiplies by the reciprocal kept here.  An
     // fp16 lo plane only carries its 11 bits while it is a normal number (|w| >= 0.25) and the hi plane underflows below
@@ -477,6 +479,14 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
                 const float ps = pack_scale({{t, 1.f}});
                 h->conv_r[i] = 1.f / ps;
                 launch_pack_conv_w(h->prec, staging, C, c_in, k, ps, h->conv_w[i], pln(h, plane), 0);
+                // layers the row-complete kernel may take (LayerNorm variant, conv_dim 512, k > 1 taps): a tap-minor copy too
+                const int tm_slice = h->NT == 2 ? 32 : 64;
+                if (!h->gn && i < cfg->n_conv - 1 && k > 1 && C == 512 && c_in % tm_slice == 0) {
+                    h->conv_w_tm[i] = alloc_planes(h, plane);
+                    if (!h->conv_w_tm[i]) { h->err = "device allocation failed"; return bail(AMX_ENOMEM); }
+                    launch_pack_conv_w(h->prec, staging, C, c_in, k, ps, h->conv_w_tm[i], pln(h, plane), 0, tm_slice);
+                    h->conv_tm_slice = tm_slice;
+                }
                 if (hipDeviceSynchronize() != hipSuccess) { h->err = "pack_conv_w failed"; return bail(AMX_EHIP); }
             }
             c_in = C;
@@ -1299,6 +1309,12 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             // AMX_NO_FUSED_CONV_LN=1: developer A/B switch (separate fp32 GEMM output + row kernel)
             const char* no_fuse = getenv("AMX_NO_FUSED_CONV_LN");
             if (!(no_fuse && no_fuse[0] == '1') && gemm_fuses_ln(prec, f)) {
+                if (h->conv_w_tm[i] && gemm_ln_tap_minor_slice(prec, f) == h->conv_tm_slice) {
+                    // tap-minor K order: the input row two output rows share is fetched in adjacent slices (an L2 hit)
+                    f.W = h->conv_w_tm[i];
+                    f.a_taps = c.conv_kernel[i];
+                    f.a_tap_stride = C;
+                }
                 { Timed t_(h, AMX_KC_GEMM_LN); run_gemm(prec, f, s); }
                 std::swap(cur, other);
                 cur_plane = out_plane;

@@ -223,6 +223,14 @@ struct GemmParams {
     // set by a caller that will run the split-K fix-up itself (launch_fixup_rownorm: fused with the LayerNorm that follows the
     // product): launch_gemm then writes the partial slabs only.  Only with gemm_planned_splits(...) > 1.
     int defer_fixup;
+    // implicit-GEMM convolutions on the row-complete kernel (gemm_ln_takes_tap_minor()): K walks the taps INSIDE a channel
+    // slice -- slice s of W (packed by launch_pack_conv_w(..., tap_minor_slice)) holds tap s % a_taps of channel slice s / a_taps,
+    // and the A operand's slice s starts (s % a_taps) * a_tap_stride + (s / a_taps) * slice elements into the row.  With k = 3,
+    // s = 2 the last tap of output row r is the first tap of row r + 1: in tap-major order the two fetches of that input row lie
+    // a third of the K loop apart (32 slices x 80 KiB x 32 workgroups per XCD: far beyond the 4 MiB L2, so every input row was
+    // fetched 1.5 times from beyond L2); tap-minor they are adjacent slices and the second one hits L2.  0 / 1: plain K order.
+    int a_taps;
+    int64_t a_tap_stride;
     unsigned long long* stamps;  // developer diagnostic (-DAMX_PP_STAMP builds of tools/gemm_bench.hip), else null
 };
 
@@ -232,6 +240,9 @@ void launch_gemm(int prec, const GemmParams& p, hipStream_t stream);
 bool gemm_uses_pp(int prec, const GemmParams& p);
 // true when a product with ln_gamma / ln_beta set can run on the row-complete kernel with fused LayerNorm + GELU
 bool gemm_fuses_ln(int prec, const GemmParams& p);
+// K elements per slice when that product will run on the whole-line kernel that understands a_taps (0: it will not -- the
+// caller then passes the tap-major weights and a_taps = 0)
+int gemm_ln_tap_minor_slice(int prec, const GemmParams& p);
 // K chunks launch_gemm will cut this product into (1: no split-K, no fix-up launch); `p` as it will be passed to launch_gemm,
 // split-K workspace included
 int gemm_planned_splits(int prec, const GemmParams& p);
@@ -351,7 +362,8 @@ void launch_pack_matrix(int prec, const float* src, int rows, int cols, int64_t 
 // that the largest weight lands in [4096, 8192): the lo plane of an fp16 pair is only a normal number, i.e. only carries its
 // full 11 bits, for |w| >= 0.25, and the hi plane underflows below 6e-5; the product's epilogue multiplies by 1 / scale)
 void launch_pack_conv_w(int prec, const float* src /*[Co,Ci,k]*/, int Co, int Ci, int k, float scale, void* dst, int64_t dst_plane,
-                        hipStream_t s);
+                        hipStream_t s, int tap_minor_slice = 0);
+// (tap_minor_slice = S > 0: K order [channel slice of S][tap][S channels] instead of [tap][channel] -- GemmParams.a_taps)
 void launch_pack_posconv_w(int prec, const float* g /*[k]*/, const float* v /*[D,cg,k]*/, int D, int cg, int k, float scale,
                            float* norm_scratch, void* dst /*[G][cg][k*cg]*/, int64_t dst_plane, hipStream_t s);
 void launch_compose(int prec, const float* emb, int E, const int64_t* idx /*[P+1, F] absolute rows, row 0 = blank*/,

@@ -63,6 +63,13 @@ bool ln_eligible(int NT, const GemmParams& p) {
     return true;
 }
 
+// the whole-line kernel (gemm_ln_il_kernel) takes the product: the one that understands the tap-minor K order
+bool ln_uses_il(int NT, const GemmParams& p) {
+    static const bool plain_loop = getenv("AMX_LN_SEGMENT_LOOP") && atoi(getenv("AMX_LN_SEGMENT_LOOP")) != 0;  // developer A/B
+    const bool layout_ok = NT == 1 || (p.a_plane == PLANE_IL && p.w_plane == PLANE_IL && p.out_plane == PLANE_IL);
+    return !plain_loop && layout_ok && p.K % (128 / NT) == 0;
+}
+
 template <typename T, int NT>
 void launch_gemm_ln(const GemmParams& p, hipStream_t stream) {
     static OncePerDevice attr;
@@ -74,9 +81,7 @@ void launch_gemm_ln(const GemmParams& p, hipStream_t stream) {
     dim3 grid(tiles < cus ? tiles : cus, 1, 1);
     {
         // whole-line operand DMA, one segment pair per K slice (two planes: interleaved operands only)
-        static const bool plain_loop = getenv("AMX_LN_SEGMENT_LOOP") && atoi(getenv("AMX_LN_SEGMENT_LOOP")) != 0;  // developer A/B
-        const bool layout_ok = NT == 1 || (p.a_plane == PLANE_IL && p.w_plane == PLANE_IL && p.out_plane == PLANE_IL);
-        if (!plain_loop && layout_ok && p.K % (128 / NT) == 0) {
+        if (ln_uses_il(NT, p)) {
             static OncePerDevice attr_il;
             if (attr_il.first())
                 (void)hipFuncSetAttribute((const void*)gemm_ln_il_kernel<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, ppi::LDS_BYTES);
@@ -383,6 +388,14 @@ static GemmParams with_vec_flag(const GemmParams& in) {
 }
 
 bool gemm_fuses_ln(int prec, const GemmParams& p_in) { return ln_eligible(prec_planes(prec), with_vec_flag(p_in)); }
+
+int gemm_ln_tap_minor_slice(int prec, const GemmParams& p_in) {
+    static const bool tap_major = getenv("AMX_LN_TAP_MAJOR") && atoi(getenv("AMX_LN_TAP_MAJOR")) != 0;  // developer A/B switch
+    const int NT = prec_planes(prec);
+    const GemmParams p = with_vec_flag(p_in);
+    if (tap_major || !ln_eligible(NT, p) || !ln_uses_il(NT, p)) return 0;
+    return NT == 2 ? 32 : 64;
+}
 
 bool gemm_uses_pp(int prec, const GemmParams& p_in) {
     const GemmParams p = with_vec_flag(p_in);

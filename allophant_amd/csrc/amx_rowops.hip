@@ -844,14 +844,25 @@ __global__ void pack_matrix_kernel(const float* __restrict__ src, int rows, int 
 
 template <typename T, int NT>
 __global__ void pack_conv_w_kernel(const float* __restrict__ src, int Co, int Ci, int k, float scale, T* __restrict__ dst,
-                                   int64_t dst_plane) {
-    // dst[co][j*Ci + ci] = src[co][ci][j]
+                                   int64_t dst_plane, int tap_minor_slice) {
+    // dst[co][j*Ci + ci] = src[co][ci][j]; tap-minor (slice S): dst[co][((ci / S) * k + j) * S + ci % S] = src[co][ci][j]
     int64_t total = (int64_t)Co * Ci * k;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int ci = (int)(i % Ci);
-        int64_t r = i / Ci;
-        int j = (int)(r % k);
-        int co = (int)(r / k);
+        int ci, j, co;
+        if (tap_minor_slice > 0) {
+            const int S = tap_minor_slice;
+            const int within = (int)(i % S);
+            int64_t r = i / S;
+            j = (int)(r % k);
+            r /= k;
+            ci = (int)(r % (Ci / S)) * S + within;
+            co = (int)(r / (Ci / S));
+        } else {
+            ci = (int)(i % Ci);
+            int64_t r = i / Ci;
+            j = (int)(r % k);
+            co = (int)(r / k);
+        }
         T hi, lo;
         split16<T, NT>(src[((int64_t)co * Ci + ci) * k + j] * scale, hi, lo);
         T* d = dst + pidx(i, plane_is_il<NT>(dst_plane));  // rows of Ci * k elements
@@ -1087,10 +1098,11 @@ void launch_pack_matrix(int prec, const float* src, int rows, int cols, int64_t 
                                           cols, src_row_stride, src_col_stride, scale, (T16*)dst, dst_plane, ldd, cols_pad));
 }
 
-void launch_pack_conv_w(int prec, const float* src, int Co, int Ci, int k, float scale, void* dst, int64_t dst_plane, hipStream_t s) {
+void launch_pack_conv_w(int prec, const float* src, int Co, int Ci, int k, float scale, void* dst, int64_t dst_plane, hipStream_t s,
+                        int tap_minor_slice) {
     int64_t total = (int64_t)Co * Ci * k;
     AMX_DISPATCH(prec, hipLaunchKernelGGL((pack_conv_w_kernel<T16, NT>), dim3(grid_for(total)), dim3(256), 0, s, src, Co, Ci, k,
-                                          scale, (T16*)dst, dst_plane));
+                                          scale, (T16*)dst, dst_plane, tap_minor_slice));
 }
 
 void launch_pack_posconv_w(int prec, const float* g, const float* v, int D, int cg, int k, float scale, float* norm_scratch, void* dst,

@@ -4,7 +4,9 @@
 //   build/attn_bench [N] [T]
 #include "../allophant_amd/csrc/amx_attention.hip"
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 using namespace amx;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
@@ -41,19 +43,94 @@ int main(int argc, char** argv) {
 #endif
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
-    for (int i = 0; i < 3; ++i) launch_attention(PREC_F16X3, p, 0);
-    CK(hipDeviceSynchronize());
-    hipEventRecord(a, 0);
-    const int reps = 20;
-    for (int i = 0; i < reps; ++i) launch_attention(PREC_F16X3, p, 0);
-    hipEventRecord(b, 0);
-    CK(hipEventSynchronize(b));
-    float ms;
-    hipEventElapsedTime(&ms, a, b);
     const double flop = 4.0 * N * H * (double)T * T * 64;
-    printf("attention f16x3 N=%d T=%d: %.1f us per launch, %.0f TFLOP/s algorithmic (x3 issued: %.0f)\n", N, T, ms * 1e3 / reps,
-           flop / (ms / reps) / 1e9, 3 * flop / (ms / reps) / 1e9);
-#ifdef AMX_ATTN_STAMP
+    const int reps = 20;
+    // attn_kernel (256-query workgroups, 32 queries per wave) against attn2_kernel (persistent 512-query workgroups, 64 queries
+    // per wave): outputs compared element by element (different softmax block sizes: close, not bitwise), then timed
+    const size_t out_elems = (size_t)2 * N * T * H * 64;
+    std::vector<unsigned short> o1(out_elems), o2(out_elems);
+    CK(hipMemset(out, 0, out_elems * 2));
+    launch_attn<f16, 2, 8, 64>(p, 0);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(o1.data(), out, out_elems * 2, hipMemcpyDeviceToHost));
+    CK(hipMemset(out, 0, out_elems * 2));
+    const int v2_waves = getenv("ATTN2_WAVES") ? atoi(getenv("ATTN2_WAVES")) : 8;
+    auto run2 = [&]() {
+        if (v2_waves == 4) launch_attn2<f16, 2, 4, 2>(p, 256, 0);
+        else if (v2_waves == 3) launch_attn4<f16, 2>(p, 256, 0);
+        else launch_attn2<f16, 2, 8, 4>(p, 256, 0);
+    };
+    run2();
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(o2.data(), out, out_elems * 2, hipMemcpyDeviceToHost));
+    {
+        auto h2f = [](unsigned short h) {
+            _Float16 x;
+            memcpy(&x, &h, 2);
+            return (float)x;
+        };
+        const size_t plane_o = (size_t)N * T * H * 64;
+        double worst = 0, scale = 0;
+        for (size_t i = 0; i < plane_o; ++i) {
+            // interleaved planes are not used here (separate planes: out_plane != 32): value = hi + lo
+            const double v1 = (double)h2f(o1[i]) + h2f(o1[i + plane_o]), v2 = (double)h2f(o2[i]) + h2f(o2[i + plane_o]);
+            worst = fmax(worst, fabs(v1 - v2));
+            scale = fmax(scale, fabs(v1));
+        }
+        printf("attn2 vs attn: max |difference| %.3e (largest output %.3f)\n", worst, scale);
+    }
+    for (int variant = 0; variant < 2; ++variant) {
+        for (int i = 0; i < 3; ++i) { if (variant) run2(); else launch_attn<f16, 2, 8, 64>(p, 0); }
+        CK(hipDeviceSynchronize());
+        hipEventRecord(a, 0);
+        for (int i = 0; i < reps; ++i) { if (variant) run2(); else launch_attn<f16, 2, 8, 64>(p, 0); }
+        hipEventRecord(b, 0);
+        CK(hipEventSynchronize(b));
+        float ms;
+        hipEventElapsedTime(&ms, a, b);
+        printf("%s f16x3 N=%d T=%d: %.1f us per launch, %.0f TFLOP/s algorithmic (x3 issued: %.0f)\n", variant ? (v2_waves == 4 ? "attn2<4 waves, 2 slots>" : v2_waves == 3 ? "attn4 (sub-blocks pipelined)" : "attn2<8 waves, 4 slots>") : "attn ", N, T,
+               ms * 1e3 / reps, flop / (ms / reps) / 1e9, 3 * flop / (ms / reps) / 1e9);
+    }
+#ifdef AMX_ATTN2_REPORT
+    {   // attn2 item anatomy: the stamps of the last attn2 launch (items x waves x 8 words)
+        const int w2 = v2_waves == 4 ? 4 : 8, qb2 = w2 * 64;
+        const int items2 = 8 * ((N * H + 7) / 8) * ((T + qb2 - 1) / qb2);
+        CK(hipMemset(st, 0, (size_t)wgs * 8 * 12 * 8));
+        run2();
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> h2((size_t)items2 * w2 * 14);
+        CK(hipMemcpy(h2.data(), st, h2.size() * 8, hipMemcpyDeviceToHost));
+        unsigned long long first = ~0ull, last = 0;
+        double pro = 0, loop = 0, epi = 0, cyc = 0, tiles = 0, cnt = 0;
+        for (size_t w = 0; w < (size_t)items2 * w2; ++w) {
+            const unsigned long long* o = &h2[w * 8];
+            if (!o[6]) continue;
+            first = o[0] < first ? o[0] : first;
+            last = o[3] > last ? o[3] : last;
+            pro += (double)(o[1] - o[0]); loop += (double)(o[2] - o[1]); epi += (double)(o[3] - o[2]);
+            cyc += (double)o[4]; tiles += (double)o[5]; cnt += 1;
+        }
+        printf("attn2 anatomy (%d waves): span %.1f us; per item and wave: prologue %.2f us, key loop %.2f us (%.2f us and %.0f cycles per tile, "
+               "clock %.2f GHz), epilogue %.2f us\n", w2, (double)(last - first) / 100.0, pro / cnt / 100.0, loop / cnt / 100.0,
+               loop / tiles / 100.0, cyc / tiles, cyc / loop / 10.0, epi / cnt / 100.0);
+        {
+            double ph[6] = {0}, ph_lo[6] = {0}, ph_hi[6] = {0}, t_lo = 0, t_hi = 0;
+            for (size_t w = 0; w < (size_t)items2 * w2; ++w) {
+                if (!h2[w * 8 + 6]) continue;
+                const unsigned long long* q = &h2[(size_t)items2 * w2 * 8 + w * 6];
+                const bool hi = (w % w2) >= (size_t)w2 / 2;
+                for (int i = 0; i < 6; ++i) { ph[i] += (double)q[i]; (hi ? ph_hi : ph_lo)[i] += (double)q[i]; }
+                (hi ? t_hi : t_lo) += (double)h2[w * 8 + 5];
+            }
+            printf("attn2 cycles per tile and wave (stamps ~40 each): DMA issue %.0f | scores %.0f | mask/max/exp %.0f | P split + PV %.0f | tile wait %.0f | "
+                   "barrier %.0f\n", ph[0] / tiles, ph[1] / tiles, ph[2] / tiles, ph[3] / tiles, ph[4] / tiles, ph[5] / tiles);
+            printf("   waves 0-3: %.0f %.0f %.0f %.0f %.0f %.0f   waves 4-7: %.0f %.0f %.0f %.0f %.0f %.0f\n", ph_lo[0] / t_lo, ph_lo[1] / t_lo,
+                   ph_lo[2] / t_lo, ph_lo[3] / t_lo, ph_lo[4] / t_lo, ph_lo[5] / t_lo, ph_hi[0] / t_hi, ph_hi[1] / t_hi, ph_hi[2] / t_hi,
+                   ph_hi[3] / t_hi, ph_hi[4] / t_hi, ph_hi[5] / t_hi);
+        }
+    }
+#endif
+#ifdef AMX_ATTN_STAMP_V1
     std::vector<unsigned long long> hs((size_t)wgs * 8 * 12);
     CK(hipMemcpy(hs.data(), st, hs.size() * 8, hipMemcpyDeviceToHost));
     double s[9] = {0};
