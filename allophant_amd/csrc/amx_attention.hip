@@ -354,21 +354,24 @@ __global__ __launch_bounds__(WAVES * 64, AMX_ATTN_OCC) void attn_kernel(const At
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// attn2_kernel (round 4): the same arithmetic on 64 queries per wave, one persistent 8-wave workgroup per CU.
+// attn2_kernel (round 4): the same arithmetic on 64 queries per wave, for long key loops.
 //
 // attn_kernel gives a wave 32 queries and runs four waves per SIMD: every wave reads the whole K and V tile from LDS for its
-// 32 queries, every 256-query workgroup DMAs all K / V tiles of its (utterance, head), and the waves of a workgroup move
-// through the score / softmax / P.V phases together (one barrier per tile), so the matrix pipe idles while they all
-// exponentiate.  Here a wave owns TWO 32-query sub-blocks: every K fragment and every V^T fragment it reads feeds both (half
-// the LDS read bytes per query), a 512-query workgroup fetches the tiles of its (utterance, head) once for twice as many
-// queries (half the L2 -> LDS bytes), and inside a wave the softmax of one sub-block sits in program order between the MFMAs
-// of the other, so one wave keeps both pipes busy.  Two waves per SIMD (<= 256 VGPRs) and a 4-slot K / V ring (128 KiB in the
-// two-plane modes) filled three tiles ahead with counted vmcnt waits; workgroups are persistent and walk (utterance, head,
-// 512-query block) items in the XCD-aware order of attn_kernel, the first tiles of the next item are DMA-ed before the
-// outputs of the current one are stored.  The online softmax steps in 32-key blocks (one accumulator set per sub-block), with
-// the same deferred maximum.  Used when 512-query items fill the chip (launch_attn_any); results are not bitwise those of
-// attn_kernel (different softmax block size), both are gated against the oracle.
-// ---------------------------------------------------------------------------------------------------------------------
+// 32 queries.  Here a wave owns TWO 32-query sub-blocks: every K fragment and every V^T fragment it reads from LDS feeds both
+// (half the LDS read bytes per query), and the DMA pieces a wave issues per tile serve twice as many queries.  Two waves per
+// SIMD (<= 256 VGPRs: 64 of Q fragments, 64 of accumulators, 32 of scores).  The online softmax steps in 32-key blocks (one
+// score accumulator set per sub-block) with the same deferred maximum, so the results are not bitwise those of attn_kernel;
+// both are gated against the oracle.  Measured per launch, f16x3 (tools/attn_bench.hip, profiles/r04_attention_experiments.log):
+//   8 x 60 s (47 key tiles per item)   attn_kernel 849-870 us   <4 waves, 2 slots> 752   <8 waves, 4 slots, persistent> 790
+//   32 x 10 s (8 key tiles per item)   attn_kernel 114-122 us   <4 waves, 2 slots> 136   <8 waves, 4 slots, persistent> 146
+// i.e. it pays from ~15 key tiles per item (launch_attn_any), where the longer prologue (Q fragments of 64 queries) and the
+// output stores of an item are small beside its key loop.  What its anatomy shows (cycle stamps, same log): the two waves of a
+// SIMD run in lockstep -- score MFMAs together (pipe-bound), exponentials together (VALU-bound), P.V together -- so matrix
+// and vector work never overlap: 10.2 k cycles per 64-key tile = 6.1 k MFMA + 4.2 k VALU.  Three attempts to overlap them
+// were built and measured slower, all for the same reason (the 256-VGPR budget): wave groups in anti-phase with a barrier
+// per segment (tools/experiments/attn3_pingpong.inc: a wave alone in its MFMA segment exposes the LDS fragment latency, and
+// prefetching fragments into registers spills), and the two sub-blocks of a wave pipelined against each other (sub-block 1
+// re-reads the fragments: 24-30 spilled registers, 965 us).
 // WAVES = 8, STAGES = 4: one 512-query workgroup per CU (ring 128 KiB), tiles three ahead.  WAVES = 4, STAGES = 2: two independent
 // 256-query workgroups per CU (64 KiB each, one tile ahead) -- their phases drift apart, so one's prologue / epilogue sits under
 // the other's key loop; the form for short key loops (10 s utterances: 8 tiles per item).
@@ -670,347 +673,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 1 : 2) void attn2_kernel(c
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// attn4_kernel: attn2_kernel<8 waves, 4 slots> with the two sub-blocks of a wave software-pipelined against each other.
-//
-// attn2 measured 10.2 k cycles per 64-key tile and wave = 6.1 k of MFMA issue (2 waves x 96 MFMAs x 32 cycles on the SIMD's
-// matrix pipe) + 4.2 k of VALU: the two waves of a SIMD pass the tile barrier together and do everything at the same time, and
-// an in-order wave does nothing else while it exponentiates.  (Putting the wave groups in anti-phase with a barrier per
-// segment -- the ping-pong of gemm_pp_kernel -- was built and was slower: 860 against 790 us at 8 x 60 s.)  The matrix pipe
-// accepts an MFMA every 32 cycles and the VALU instructions a wave issues in between are free while they fit that gap
-// (MI355X_MICROARCH.md, "Two waves per SIMD", item 1), so here the softmax of one sub-block sits BETWEEN the MFMAs of the other
-// one in program order, per 32-key block:
-//     A   S(sb0): 12 MFMAs
-//     B   S(sb1): 12 MFMAs   ||  maximum / exp / row sum / hi-lo split of sb0
-//     C   P.V(sb0): 12 MFMAs ||  the same of sb1
-//     D   P.V(sb1): 12 MFMAs
-// The price: sb1 re-reads the K fragments and the V^T fragments from LDS (keeping them would need 32 + 32 more VGPRs than the
-// 256 a wave has at two waves per SIMD), i.e. the LDS read bytes per query of attn_kernel.  The deferred-maximum branch sits
-// behind the first K slice of phase B / the first V^T fragment pair of phase C (a branch ends the compiler's scheduling
-// region); blocks with masked keys take a plain, unpipelined body.
-// ---------------------------------------------------------------------------------------------------------------------
-template <typename T, int NT, bool PACKED>
-__global__ __launch_bounds__(512, 1) void attn4_kernel(const AttnParams p, int total_items) {
-    constexpr int WAVES = 8, KT = 64, SUB = 2, STAGES = 4;
-    constexpr int TILE = KT * 128;        // bytes of one K or V tile of one plane
-    constexpr int STAGE = NT * 2 * TILE;  // [plane][K tile | V tile]
-    constexpr int QB = WAVES * 32 * SUB;  // 512 queries per item
-    typedef typename Vec8<T>::type V8;
-    typedef typename Vec4<T>::type V4;
-    typedef typename Vec2<T>::type V2;
-    typedef short s16x4 __attribute__((__vector_size__(8)));
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    typedef __attribute__((address_space(3))) s16x4* lds_s4_t;
-    union P8 { V2 h[4]; V8 v; };
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hh = lane >> 5, lq = lane & 31;
-    const int qblocks = (p.T + QB - 1) / QB;
-    const uint32_t plane_b = (uint32_t)(p.qk_plane * 2);
-
-    const uint32_t voff_k = (uint32_t)((lane >> 3) * 128 + (((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) << 4));
-    const uint32_t voff_v = (uint32_t)((lane >> 3) * 128 + (((lane & 7) ^ (4 * ((lane >> 4) & 1))) << 4));
-    const int kaddr0 = lq * 128 + ((hh ^ ((lq >> 1) & 7)) << 4);
-    int vaddr[2];
-    {
-        const int q4 = (lane & 15) >> 2, pp = lane & 3;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-            vaddr[dt] = TILE + (4 * hh + q4) * 128 + 64 * (dt ^ ((q4 >> 1) & 1)) + 32 * ((lane >> 4) & 1) + 8 * pp;
-    }
-
-    struct Item { int n, h, qblock, klen, roff, nkt; int64_t first; bool live; };
-    auto decode = [&](int item) {
-        Item it;
-        const int slot = item >> 3;
-        const int nh = (slot / qblocks) * 8 + (item & 7);
-        it.qblock = slot % qblocks;
-        it.live = item < total_items && nh < p.N * p.H;
-        const int nhc = it.live ? nh : 0;
-        it.h = nhc % p.H;
-        it.n = PACKED && p.order ? p.order[nhc / p.H] : nhc / p.H;
-        int klen = p.frame_len[it.n];
-        klen = klen < 1 ? 1 : (klen > p.T ? p.T : klen);
-        it.klen = klen;
-        it.nkt = (klen + KT - 1) / KT;
-        it.roff = PACKED ? p.row_off[it.n] : 0;
-        if (PACKED && it.qblock * QB >= klen) it.live = false;
-        it.first = PACKED ? ((int64_t)it.h * p.Tp + it.roff) * DH : (int64_t)nhc * p.Tp * DH;
-        return it;
-    };
-    auto stage = [&](const Item& it, int kt) {
-        const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.k + it.first), 0, -1, 0x00020000);
-        const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.v + it.first), 0, -1, 0x00020000);
-#pragma unroll
-        for (int pl = 0; pl < NT; ++pl) {
-            const uint32_t so = (uint32_t)kt * TILE + pl * plane_b + wave * 1024;
-            unsigned char* dst = smem + (kt & (STAGES - 1)) * STAGE + pl * 2 * TILE + wave * 1024;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_ptr_t)dst, 16, voff_k, so, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lds_ptr_t)(dst + TILE), 16, voff_v, so, 0, 0);
-        }
-    };
-    auto stage_head = [&](const Item& it) {
-        if (!it.live) return;
-        stage(it, 0);
-        if (it.nkt > 1) stage(it, 1);
-        if (it.nkt > 2) stage(it, 2);
-    };
-
-    Item cur = decode(blockIdx.x);
-    stage_head(cur);
-    for (int item = blockIdx.x; item < total_items; item += gridDim.x) {
-        const Item nxt = decode(item + gridDim.x);
-        if (!cur.live) {
-            cur = nxt;
-            stage_head(cur);
-            continue;
-        }
-        const int klen = cur.klen, nkt = cur.nkt;
-        const int q_rows = PACKED ? p.Tp - cur.roff : p.Tp;
-        const T* Qb = (const T*)p.q + cur.first;
-        const int q_base = cur.qblock * QB + wave * 32 * SUB;
-
-        V8 qf[SUB][NT][4];
-#pragma unroll
-        for (int sb = 0; sb < SUB; ++sb) {
-            const int query = q_base + 32 * sb + lq;
-            const int qr = query < q_rows ? query : q_rows - 1;
-#pragma unroll
-            for (int pl = 0; pl < NT; ++pl)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-                    qf[sb][pl][ks] = *(const V8*)(Qb + (int64_t)pl * p.qk_plane + (int64_t)qr * DH + ks * 16 + 8 * hh);
-        }
-        f32x16 O[SUB][2];
-        float m_run[SUB], l_run[SUB];
-#pragma unroll
-        for (int sb = 0; sb < SUB; ++sb) {
-            m_run[sb] = 0.f;
-            l_run[sb] = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { O[sb][0][r] = 0.f; O[sb][1][r] = 0.f; }
-        }
-        bool first_block = true;
-
-        // one K slice (16 of the 64 head dimensions) of the scores of sub-block sb: 3 MFMAs (two planes), fragments read here
-        auto s_slice = [&](const unsigned char* kb, int ks, int sb, f32x16& X) {
-            const V8 kf = *(const V8*)(kb + (kaddr0 ^ (ks << 5)));
-            if (NT > 1) {
-                const V8 kl = *(const V8*)(kb + 2 * TILE + (kaddr0 ^ (ks << 5)));
-                X = mfma32(kl, qf[sb][0][ks], X);
-                X = mfma32(kf, qf[sb][NT - 1][ks], X);
-            }
-            X = mfma32(kf, qf[sb][0][ks], X);
-        };
-        // one V^T fragment pair (16 keys x 32 head dimensions) of P.V of sub-block sb: 3 MFMAs
-        auto pv_frag = [&](const unsigned char* kb, int s2, int dt, const P8& ph, const P8& pl_, f32x16& Oacc) {
-            const int koff = s2 * 2048;
-            union { s16x4 h[2]; V8 v; } vf, vl;
-            vf.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(kb + koff + vaddr[dt]));
-            vf.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(kb + koff + 1024 + vaddr[dt]));
-            if (NT > 1) {
-                vl.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(kb + 2 * TILE + koff + vaddr[dt]));
-                vl.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(kb + 2 * TILE + koff + 1024 + vaddr[dt]));
-                Oacc = mfma32(vl.v, ph.v, Oacc);
-                Oacc = mfma32(vf.v, pl_.v, Oacc);
-            }
-            Oacc = mfma32(vf.v, ph.v, Oacc);
-        };
-        // maximum of a sub-block's 32 x 32 scores per query (both lane halves)
-        auto block_max = [&](const f32x16& X) {
-            float t0 = fmaxf(fmaxf(X[0], X[1]), X[2]), t1 = fmaxf(fmaxf(X[3], X[4]), X[5]);
-#pragma unroll
-            for (int r = 6; r + 3 < 16; r += 4) {
-                t0 = fmaxf(fmaxf(t0, X[r]), X[r + 1]);
-                t1 = fmaxf(fmaxf(t1, X[r + 2]), X[r + 3]);
-            }
-            const float mx = fmaxf(fmaxf(t0, t1), fmaxf(X[14], X[15]));
-            return fmaxf(mx, __shfl_xor(mx, 32));
-        };
-        // the rare path of the deferred maximum (always on the first block): move m_run, rescale O and l_run, shift the scores
-        auto rescale = [&](int sb, float mx, f32x16& X) {
-            const float d = first_block ? mx : fmaxf(mx, 0.f);
-            const float alpha = __builtin_amdgcn_exp2f(-d);
-            m_run[sb] += d;
-            l_run[sb] *= alpha;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { O[sb][0][r] *= alpha; O[sb][1][r] *= alpha; X[r] -= d; }
-        };
-        // exp, row sum and the hi / lo planes of the probabilities (X is dead afterwards)
-        auto finish = [&](int sb, f32x16& X, P8 (&ph)[2], P8 (&pl_)[2]) {
-            f32x2 ps = {0.f, 0.f};
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const f32x2 e = {__builtin_amdgcn_exp2f(X[r]), __builtin_amdgcn_exp2f(X[r + 1])};
-                ps += e;
-                const V2 hi = __builtin_convertvector(e, V2);
-                ph[r >> 3].h[(r >> 1) & 3] = hi;
-                if (NT > 1) {
-                    const f32x2 back = {(float)hi[0], (float)hi[1]};
-                    pl_[r >> 3].h[(r >> 1) & 3] = __builtin_convertvector(e - back, V2);
-                }
-            }
-            l_run[sb] += ps[0] + ps[1];
-        };
-
-        for (int kt = 0; kt < nkt; ++kt) {
-            const int ahead = nkt - 1 - kt;
-            if (ahead >= 2) {
-                if (NT == 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-            } else if (ahead == 1) {
-                if (NT == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_s_barrier();
-            if (kt + 3 < nkt) stage(cur, kt + 3);
-            const unsigned char* sbuf = smem + (kt & (STAGES - 1)) * STAGE;
-            const int kb0 = kt * KT;
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                if (kb0 + 32 * c >= klen) break;  // a 32-key block wholly beyond the utterance (wave-uniform)
-                const unsigned char* kb = sbuf + c * 4096;
-                f32x16 X0, X1;
-                P8 ph0[2], pl0[2], ph1[2], pl1[2];
-                if (kb0 + 32 * c + 32 > klen) {
-                    // ---- a block with masked keys (the last one of an utterance): plain body ----
-                    const int rem = klen - kb0 - 32 * c - 4 * hh;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) { X0[r] = -m_run[0]; X1[r] = -m_run[1]; }
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) { s_slice(kb, ks, 0, X0); s_slice(kb, ks, 1, X1); }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const bool ok = (r & 3) + 8 * (r >> 2) < rem;
-                        X0[r] = ok ? X0[r] : -INFINITY;
-                        X1[r] = ok ? X1[r] : -INFINITY;
-                    }
-                    const float mx0 = block_max(X0), mx1 = block_max(X1);
-                    if (first_block || !__all(mx0 <= DEFER_THR)) rescale(0, mx0, X0);
-                    if (first_block || !__all(mx1 <= DEFER_THR)) rescale(1, mx1, X1);
-                    finish(0, X0, ph0, pl0);
-                    finish(1, X1, ph1, pl1);
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                        for (int dt = 0; dt < 2; ++dt) {
-                            pv_frag(kb, s2, dt, ph0[s2], pl0[s2], O[0][dt]);
-                            pv_frag(kb, s2, dt, ph1[s2], pl1[s2], O[1][dt]);
-                        }
-                    first_block = false;
-                    continue;
-                }
-                // ---- A: scores of sub-block 0 ----
-                {
-                    const float neg_m = -m_run[0];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) X0[r] = neg_m;
-                }
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) s_slice(kb, ks, 0, X0);
-                // ---- B: scores of sub-block 1 beside the softmax of sub-block 0 ----
-                {
-                    const float neg_m = -m_run[1];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) X1[r] = neg_m;
-                }
-                s_slice(kb, 0, 1, X1);
-                const float mx0 = block_max(X0);
-                if (first_block || !__all(mx0 <= DEFER_THR)) rescale(0, mx0, X0);
-#pragma unroll
-                for (int ks = 1; ks < 4; ++ks) s_slice(kb, ks, 1, X1);
-                finish(0, X0, ph0, pl0);
-                // (9 MFMAs, each followed by its share of the 16 exp + 56 other VALU instructions of `finish`)
-#ifdef AMX_A4_HINTS
-#pragma unroll
-                for (int i = 0; i < 9; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x2, 8, 0);
-                }
-#endif
-                // ---- C: P.V of sub-block 0 beside the softmax of sub-block 1 ----
-                pv_frag(kb, 0, 0, ph0[0], pl0[0], O[0][0]);
-                const float mx1 = block_max(X1);
-                if (first_block || !__all(mx1 <= DEFER_THR)) rescale(1, mx1, X1);
-                pv_frag(kb, 0, 1, ph0[0], pl0[0], O[0][1]);
-                pv_frag(kb, 1, 0, ph0[1], pl0[1], O[0][0]);
-                pv_frag(kb, 1, 1, ph0[1], pl0[1], O[0][1]);
-                finish(1, X1, ph1, pl1);
-#ifdef AMX_A4_HINTS
-#pragma unroll
-                for (int i = 0; i < 9; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 1);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);
-                    __builtin_amdgcn_sched_group_barrier(0x2, 8, 1);
-                }
-#endif
-                // ---- D: P.V of sub-block 1 ----
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) pv_frag(kb, s2, dt, ph1[s2], pl1[s2], O[1][dt]);
-                first_block = false;
-            }
-        }
-        // every wave is done with the ring before the next item's first tiles overwrite its first slots
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        stage_head(nxt);  // ... in flight under the output stores below
-
-        const bool o_il = plane_is_il<NT>(p.out_plane);
-#pragma unroll
-        for (int sb = 0; sb < SUB; ++sb) {
-            const int query = q_base + 32 * sb + lq;
-            const float l_tot = l_run[sb] + __shfl_xor(l_run[sb], 32);
-            const float inv = 1.0f / l_tot;
-            if (query < (PACKED ? klen : p.T)) {
-                T* dst = (T*)p.out + pidx(((PACKED ? (int64_t)cur.roff : (int64_t)cur.n * p.T) + query) * (p.H * DH) + cur.h * DH, o_il);
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        V4 hv, lv;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            T hi, lo = (T)0.f;
-                            split16<T, NT>(O[sb][dt][4 * g + j] * inv, hi, lo);
-                            hv[j] = hi;
-                            lv[j] = lo;
-                        }
-                        const int d0 = (dt * 32 << (o_il ? 1 : 0)) + 8 * g + 4 * hh;
-                        *(V4*)(dst + d0) = hv;
-                        if (NT > 1) *(V4*)(dst + p.out_plane + d0) = lv;
-                    }
-            }
-        }
-        cur = nxt;
-    }
-}
-
-template <typename T, int NT>
-void launch_attn4(const AttnParams& p, int cus, hipStream_t stream) {
-    constexpr int lds = 4 * NT * 2 * 64 * 128;
-    const int qblocks = (p.T + 511) / 512;
-    const int items = 8 * ((p.N * p.H + 7) / 8) * qblocks;
-    int grid = cus - cus % 8;  // the item order assumes that workgroups i and i + grid share an XCD
-    if (grid < 8) grid = 8;
-    if (grid > items) grid = items;
-    if (p.row_off) {
-        static OncePerDevice attr;
-        if (attr.first()) (void)hipFuncSetAttribute((const void*)attn4_kernel<T, NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL((attn4_kernel<T, NT, true>), dim3((unsigned)grid), dim3(512), lds, stream, p, items);
-    } else {
-        static OncePerDevice attr;
-        if (attr.first()) (void)hipFuncSetAttribute((const void*)attn4_kernel<T, NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL((attn4_kernel<T, NT, false>), dim3((unsigned)grid), dim3(512), lds, stream, p, items);
-    }
-}
-
 template <typename T, int NT, bool PACKED, int WAVES, int STAGES>
 void launch_attn2_layout(const AttnParams& p, int cus, hipStream_t stream) {
     static_assert(WAVES == 8 || STAGES == 2, "the counted waits of the 4-slot ring assume one DMA piece per wave");
@@ -1024,6 +686,11 @@ void launch_attn2_layout(const AttnParams& p, int cus, hipStream_t stream) {
     int grid = (cus - cus % 8) * (WAVES == 8 ? 1 : 2);  // the item order assumes that workgroups i and i + grid share an XCD
     if (grid < 8) grid = 8;
     if (grid > items) grid = items;
+    // WAVES == 4: one item per workgroup -- the hardware dispatcher hands them out as workgroups retire, which balances the two
+    // workgroups of a CU (the younger one loses the issue arbitration and runs ~20 % slower: with a static split of the items
+    // it sets the span).  AMX_ATTN2_PERSISTENT=1: developer A/B switch
+    static const bool persistent4 = getenv("AMX_ATTN2_PERSISTENT") && atoi(getenv("AMX_ATTN2_PERSISTENT")) != 0;
+    if (WAVES == 4 && !persistent4) grid = items;
     hipLaunchKernelGGL((attn2_kernel<T, NT, PACKED, WAVES, STAGES>), dim3((unsigned)grid), dim3(WAVES * 64), lds, stream, p, items);
 }
 
@@ -1070,16 +737,14 @@ void launch_attn_any(const AttnParams& p, hipStream_t stream) {
     const int64_t wg8 = (int64_t)p.N * p.H * ((p.T + 255) / 256);
     static const int force = getenv("AMX_ATTN_WAVES") ? atoi(getenv("AMX_ATTN_WAVES")) : 0;  // developer A/B switch
     {
-        // 64 queries per wave, 512 per (persistent) workgroup -- attn2_kernel -- when such items keep every CU busy and the
-        // 512-query blocks waste no more queries than the 256-query ones (AMX_ATTN_V2 = 0 / 1 forces the choice: A/B switch)
+        // 64 queries per wave (attn2_kernel, 256-query workgroups) for long key loops on a full chip (AMX_ATTN_V2 = 0 / 1 forces
+        // the choice: developer A/B switch)
         static const int v2 = getenv("AMX_ATTN_V2") ? atoi(getenv("AMX_ATTN_V2")) : -1;
-        const int64_t items = (int64_t)p.N * p.H * ((p.T + 511) / 512);
-        const int64_t q512 = (int64_t)((p.T + 511) / 512) * 512, q256 = (int64_t)((p.T + 255) / 256) * 256;
-        // (measured: 8 x 60 s 870 -> 790 us per launch; at 10 s utterances -- 8 key tiles per item -- the per-item prologue and
-        // store burst of 512-query items cost more than the key loop gains: 122 -> 146 us)
-        const bool fits = items >= cus && q512 * 10 <= q256 * 11 && p.T >= 1536;
+        // (crossover measured at 12-15 key tiles per item with the chip full: T = 749 123 -> 147 us, T = 999 235 -> 221,
+        // T = 1499 246 -> 234, T = 1999 640 -> 558, T = 2999 849 -> 752; one utterance alone keeps the 32-query waves)
+        const bool fits = wg8 * 2 >= 3 * (int64_t)cus && p.T >= 960;
         if (v2 == 1 || (v2 < 0 && fits && !force)) {
-            launch_attn2<T, NT, 8, 4>(p, cus, stream);
+            launch_attn2<T, NT, 4, 2>(p, cus, stream);
             return;
         }
     }

@@ -3,6 +3,8 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iallophant_amd/csrc -Iinclude [-DAMX_ATTN_STAMP] -o build/attn_bench tools/attn_bench.hip
 //   build/attn_bench [N] [T]
 #include "../allophant_amd/csrc/amx_attention.hip"
+#include "experiments/attn3_pingpong.inc"
+#include "experiments/attn4_subblock_pipeline.inc"
 #include <cstdio>
 #include <cmath>
 #include <cstdlib>
@@ -58,6 +60,7 @@ int main(int argc, char** argv) {
     auto run2 = [&]() {
         if (v2_waves == 4) launch_attn2<f16, 2, 4, 2>(p, 256, 0);
         else if (v2_waves == 3) launch_attn4<f16, 2>(p, 256, 0);
+        else if (v2_waves == 5) launch_attn3<f16, 2>(p, 256, 0);
         else launch_attn2<f16, 2, 8, 4>(p, 256, 0);
     };
     run2();
@@ -88,10 +91,29 @@ int main(int argc, char** argv) {
         CK(hipEventSynchronize(b));
         float ms;
         hipEventElapsedTime(&ms, a, b);
-        printf("%s f16x3 N=%d T=%d: %.1f us per launch, %.0f TFLOP/s algorithmic (x3 issued: %.0f)\n", variant ? (v2_waves == 4 ? "attn2<4 waves, 2 slots>" : v2_waves == 3 ? "attn4 (sub-blocks pipelined)" : "attn2<8 waves, 4 slots>") : "attn ", N, T,
+        printf("%s f16x3 N=%d T=%d: %.1f us per launch, %.0f TFLOP/s algorithmic (x3 issued: %.0f)\n", variant ? (v2_waves == 4 ? "attn2<4 waves, 2 slots>" : v2_waves == 5 ? "attn3 (ping-pong groups)" : v2_waves == 3 ? "attn4 (sub-blocks pipelined)" : "attn2<8 waves, 4 slots>") : "attn ", N, T,
                ms * 1e3 / reps, flop / (ms / reps) / 1e9, 3 * flop / (ms / reps) / 1e9);
     }
 #ifdef AMX_ATTN2_REPORT
+    if (v2_waves == 5) {
+        CK(hipMemset(st, 0, (size_t)wgs * 8 * 12 * 8));
+        run2();
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> h3((size_t)256 * 8 * 8);
+        CK(hipMemcpy(h3.data(), st, h3.size() * 8, hipMemcpyDeviceToHost));
+        for (int g = 0; g < 2; ++g) {
+            double ph[4] = {0}, tiles = 0;
+            for (int wg = 0; wg < 256; ++wg)
+                for (int w = 4 * g; w < 4 * g + 4; ++w) {
+                    const unsigned long long* o = &h3[((size_t)wg * 8 + w) * 8];
+                    for (int i = 0; i < 4; ++i) ph[i] += (double)o[i];
+                    tiles += (double)o[4];
+                }
+            if (tiles > 0)
+                printf("attn3 group %d, cycles per tile and wave: scores %.0f | barrier behind them %.0f | DMA + softmax + PV + tile wait %.0f (softmax part %.0f) | barrier %.0f\n",
+                       g, ph[0] / tiles, ph[1] / tiles - 0, ph[2] / tiles, 0.0, ph[3] / tiles);
+        }
+    } else
     {   // attn2 item anatomy: the stamps of the last attn2 launch (items x waves x 8 words)
         const int w2 = v2_waves == 4 ? 4 : 8, qb2 = w2 * 64;
         const int items2 = 8 * ((N * H + 7) / 8) * ((T + qb2 - 1) / qb2);
