@@ -223,9 +223,10 @@ struct GemmParams {
     // set by a caller that will run the split-K fix-up itself (launch_fixup_rownorm: fused with the LayerNorm that follows the
     // product): launch_gemm then writes the partial slabs only.  Only with gemm_planned_splits(...) > 1.
     int defer_fixup;
-    // implicit-GEMM convolutions on the row-complete kernel (gemm_ln_takes_tap_minor()): K walks the taps INSIDE a channel
-    // slice -- slice s of W (packed by launch_pack_conv_w(..., tap_minor_slice)) holds tap s % a_taps of channel slice s / a_taps,
-    // and the A operand's slice s starts (s % a_taps) * a_tap_stride + (s / a_taps) * slice elements into the row.  With k = 3,
+    // implicit-GEMM convolutions on the row-complete kernel (gemm_ln_tap_minor_slice()): K walks the taps INSIDE a channel
+    // slice -- slice s of W (packed by launch_pack_conv_w(..., tap_minor_slice)) holds tap (a_taps - s % a_taps) % a_taps (order
+    // 0, 2, 1 for three taps) of channel slice s / a_taps, and the A operand's slice s starts tap * a_tap_stride + (s / a_taps) *
+    // slice elements into the row.  With k = 3,
     // s = 2 the last tap of output row r is the first tap of row r + 1: in tap-major order the two fetches of that input row lie
     // a third of the K loop apart (32 slices x 80 KiB x 32 workgroups per XCD: far beyond the 4 MiB L2, so every input row was
     // fetched 1.5 times from beyond L2); tap-minor they are adjacent slices and the second one hits L2.  0 / 1: plain K order.

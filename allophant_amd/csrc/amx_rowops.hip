@@ -845,7 +845,7 @@ __global__ void pack_matrix_kernel(const float* __restrict__ src, int rows, int 
 template <typename T, int NT>
 __global__ void pack_conv_w_kernel(const float* __restrict__ src, int Co, int Ci, int k, float scale, T* __restrict__ dst,
                                    int64_t dst_plane, int tap_minor_slice) {
-    // dst[co][j*Ci + ci] = src[co][ci][j]; tap-minor (slice S): dst[co][((ci / S) * k + j) * S + ci % S] = src[co][ci][j]
+    // dst[co][j*Ci + ci] = src[co][ci][j]; tap-minor (slice S): dst[co][((ci / S) * k + pos) * S + ci % S] = src[co][ci][(k - pos) % k]
     int64_t total = (int64_t)Co * Ci * k;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         int ci, j, co;
@@ -854,6 +854,7 @@ __global__ void pack_conv_w_kernel(const float* __restrict__ src, int Co, int Ci
             const int within = (int)(i % S);
             int64_t r = i / S;
             j = (int)(r % k);
+            j = (k - j) % k;  // position 0, 1, 2 of a channel slice holds tap 0, 2, 1 (GemmParams.a_taps: shared rows back to back)
             r /= k;
             ci = (int)(r % (Ci / S)) * S + within;
             co = (int)(r / (Ci / S));
