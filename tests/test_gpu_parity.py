@@ -464,6 +464,12 @@ def test_random_models_and_geometries_against_oracle(amd, seed):
 
     rng = np.random.default_rng(1000 + seed)
     spec = _random_spec(rng)
+    # the wav2vec 2.0 variant switches, drawn from a generator of their own (the graphs and geometries of a seed stay what they
+    # were): odd seeds take a random combination of extractor norm, conv bias, layer ordering and attention mask
+    if seed % 2:
+        vrng = np.random.default_rng(5000 + seed)
+        spec.update(feat_extract_norm="group" if vrng.integers(0, 2) else "layer", conv_bias=bool(vrng.integers(0, 2)),
+                    stable_layer_norm=bool(vrng.integers(0, 2)), use_attention_mask=bool(vrng.integers(0, 2)))
     state = synthetic.make_state_dict(spec, seed=seed)
     composed = bool(spec.get("embedding_size"))
     est = amd.Estimator(spec, state, "cuda:0", "f16x3")
