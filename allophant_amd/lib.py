@@ -29,7 +29,7 @@ LIB_PATH = os.environ.get("AMX_LIB_PATH") or os.path.join(os.path.dirname(os.pat
 EXPORTS = [
     "amx_create", "amx_destroy", "amx_last_error", "amx_set_inventory", "amx_output_layout", "amx_forward",
     "amx_synchronize", "amx_greedy_ctc", "amx_debug_fetch", "amx_device_bytes", "amx_timing_fetch",
-    "amx_max_utterances", "amx_greedy_ctc_emissions", "amx_check_finite",
+    "amx_max_utterances", "amx_greedy_ctc_emissions", "amx_check_finite", "amx_gather_outputs", "amx_dist_last_error",
 ]
 
 
@@ -109,6 +109,10 @@ def load() -> C.CDLL:
     lib.amx_max_utterances.restype = i64
     lib.amx_greedy_ctc_emissions.argtypes = [i32, vp, i64, i64, vp, i32, i64, i32, i32, vp, vp, vp, vp, vp]
     lib.amx_greedy_ctc_emissions.restype = i32
+    lib.amx_gather_outputs.argtypes = [vp, i32, i32, i32, vp, i64, vp, vp, i32, vp, vp]
+    lib.amx_gather_outputs.restype = i32
+    lib.amx_dist_last_error.argtypes = []
+    lib.amx_dist_last_error.restype = C.c_char_p
     _lib = lib
     return lib
 

@@ -224,6 +224,21 @@ int amx_timing_fetch(amx_handle h, float* ms, int32_t* launches, int n_classes);
 /* number of bytes of device memory held by the handle (weights + workspace) */
 int64_t amx_device_bytes(amx_handle h);
 
+/* The exchange step of utterance-level data parallelism (no upstream counterpart: the reference is single-device,
+ * run.py:576-580) for hosts that do not use allophant_amd/parallel.py: one process per GPU, every rank
+ * runs amx_forward on its contiguous block of utterances and calls this with the SAME `count` (floats of its output block,
+ * amx_output_layout of the shard geometry; equal shards) and `n_local` (utterances of a shard).  The root rank receives the
+ * blocks in rank order into `recv` (world x count floats) and the frame lengths into `recv_lengths` (world x n_local int64);
+ * block r holds, per output, the [T, n_local, C] tensor of rank r's utterances at the offsets amx_output_layout reports.
+ * `send`, `recv`, `send_lengths`, `recv_lengths` are DEVICE pointers (copy `out_lengths` of amx_forward to the device first);
+ * `recv` / `recv_lengths` may be NULL on the other ranks.  `nccl_comm` is an ncclComm_t the caller created (ncclCommInitRank, one
+ * communicator per process); the work is enqueued on `stream` behind the forward pass, RCCL moves it over xGMI.  The library does
+ * not link RCCL: it uses the ncclSend / ncclRecv of the RCCL already loaded in the process -- the one the communicator came from
+ * (AMX_ESTATE if there is none).  Errors: amx_dist_last_error(). */
+int amx_gather_outputs(void* nccl_comm, int rank, int world, int root, const float* send, int64_t count, float* recv,
+                       const int64_t* send_lengths, int n_local, int64_t* recv_lengths, void* stream);
+const char* amx_dist_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

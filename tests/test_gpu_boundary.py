@@ -433,3 +433,61 @@ def test_small_entry_points(amd):
     assert code != 0 and not handle.value
     with pytest.raises(ValueError, match="ABI version"):
         L.check(lib, None, code)
+
+
+def test_c_abi_gather_over_a_one_rank_rccl_communicator(amd):
+    """`amx_gather_outputs`: the exchange step of data parallelism behind the C ABI, for hosts that do not go through
+    torch.distributed.  A communicator of ONE rank (all this box has) created with the RCCL under /opt/rocm through ctypes, the
+    way a C host would with ncclCommInitRank: the root's receive buffers must hold this rank's output block and frame lengths
+    bit for bit, and the [T, N, C] views of the received block at the offsets of amx_output_layout must equal the prediction."""
+    import ctypes as C
+    import os
+
+    path = "/opt/rocm/lib/librccl.so"
+    if not os.path.exists(path):
+        pytest.skip("no RCCL under /opt/rocm")
+    os.environ["AMX_RCCL_LIBRARY"] = path  # the library resolves ncclSend / ncclRecv in the RCCL the communicator comes from
+    rccl = C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid = UniqueId()
+    rccl.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    torch.cuda.set_device(0)
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+
+    from allophant_amd import lib as L
+
+    handle = L.load()
+    spec = S.multitask_spec(S.tiny_encoder(2), ["syllabic", "long"], embedding_size=16, train_phonemes=9, n_features=5)
+    state = synthetic.make_state_dict(spec, seed=3)
+    est = amd.Estimator(spec, state, "cuda:0", "f16x3")
+    audio, lengths = synthetic.make_audio(3, 5000, seed=5, ragged=True)
+    tfi = synthetic.make_inventory(spec, 6, seed=3)
+    pred = est.predict(amd.Batch(audio.cuda(), lengths, torch.zeros(3, dtype=torch.long)), tfi)
+    flat = pred._flat
+    frame_lengths = pred.lengths.to("cuda:0")
+    received = torch.full_like(flat, float("nan"))
+    received_lengths = torch.full_like(frame_lengths, -1)
+    stream = torch.cuda.current_stream().cuda_stream
+    code = handle.amx_gather_outputs(comm, 0, 1, 0, C.c_void_p(flat.data_ptr()), flat.numel(), C.c_void_p(received.data_ptr()),
+                                     C.c_void_p(frame_lengths.data_ptr()), 3, C.c_void_p(received_lengths.data_ptr()), C.c_void_p(stream))
+    assert code == 0, handle.amx_dist_last_error().decode()
+    torch.cuda.synchronize()
+    assert torch.equal(received, flat) and torch.equal(received_lengths, frame_lengths)
+    first = flat.data_ptr()
+    for name, out in pred.outputs.items():
+        offset = (out.data_ptr() - first) // 4
+        t, n, c = out.shape
+        assert torch.equal(received[offset: offset + t * n * c].view(t, n, c), out), name
+    # argument errors are refused before anything is enqueued
+    assert handle.amx_gather_outputs(comm, 0, 1, 0, None, flat.numel(), None, None, 3, None, C.c_void_p(stream)) == L.AMX_EINVAL
+    assert handle.amx_gather_outputs(None, 0, 1, 0, C.c_void_p(flat.data_ptr()), 1, C.c_void_p(received.data_ptr()), None, 0, None,
+                                     C.c_void_p(stream)) == L.AMX_EINVAL
+    assert rccl.ncclCommDestroy(comm) == 0
+    est.close()
