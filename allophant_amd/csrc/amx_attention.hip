@@ -36,13 +36,19 @@ constexpr float DEFER_THR = 8.0f;  // log2 units
 // waves per SIMD the register allocation must allow: two 8-wave workgroups or four 4-wave / 32-key workgroups per CU -> 4;
 // two 4-wave / 64-key workgroups -> 2
 #ifndef AMX_ATTN_OCC
-#define AMX_ATTN_OCC ((WAVES == 8 || KT == 32) ? 4 : 2)
+#define AMX_ATTN_OCC ((KS == 1 && (WAVES == 8 || KT == 32)) ? 4 : 2)
 #endif
 // KT = keys per tile (64; a 32-key instance with four 4-wave workgroups per CU was 5 % slower at 32 x 10 s)
 // PACKED: the packed-row layout of a ragged batch (AttnParams.row_off), a compile-time variant so that the padded kernel
 // keeps its code
-template <typename T, int NT, int WAVES, int KT, bool PACKED>
-__global__ __launch_bounds__(WAVES * 64, AMX_ATTN_OCC) void attn_kernel(const AttnParams p) {
+// KS = 2 (round 4, short batches): the key tiles of a query block are split over TWO halves of the workgroup -- waves [0, WAVES)
+// take the first half of the utterance's key tiles, waves [WAVES, 2 WAVES) the second half, each half with a K / V ring of its
+// own -- and the halves' (maximum, row sum, O) are merged through LDS in a fixed order at the end.  When the grid is one
+// workgroup per CU or less anyway (4 x 10 s: 256 workgroups of 128 queries), the serial key loop of a wave IS the launch; two
+// waves per SIMD halve it.  Every query's result is that of one wave with the same tiles in two groups: not bitwise the KS = 1
+// result (different rescale points), same gate.
+template <typename T, int NT, int WAVES, int KT, bool PACKED, int KS = 1>
+__global__ __launch_bounds__(WAVES * KS * 64, AMX_ATTN_OCC) void attn_kernel(const AttnParams p) {
     constexpr int TILE = KT * 128;     // bytes of one K or V tile of one plane
     constexpr int NC = KT / 32;        // 32-key blocks per tile
     typedef typename Vec8<T>::type V8;
@@ -57,7 +63,10 @@ __global__ __launch_bounds__(WAVES * 64, AMX_ATTN_OCC) void attn_kernel(const At
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = KS == 1 ? wave_all : wave_all % WAVES;  // position among the query waves
+    const int kh = KS == 1 ? 0 : wave_all / WAVES;           // key half of this wave
+    unsigned char* const ring = smem + kh * 2 * STAGE;
     const int hh = lane >> 5, lq = lane & 31;
     // XCD-aware order (1-D grid): workgroups are dealt round-robin over the 8 XCDs, so the query blocks of one (utterance,
     // head) are given consecutive slots of ONE XCD: they run side by side and the K / V tiles one of them pulls into that
@@ -76,6 +85,10 @@ __global__ __launch_bounds__(WAVES * 64, AMX_ATTN_OCC) void attn_kernel(const At
     int klen = p.frame_len[n];
     klen = klen < 1 ? 1 : (klen > p.T ? p.T : klen);
     const int nkt = (klen + KT - 1) / KT;
+    // KS == 2: this wave's share of the key tiles -- tiles kt0 .. kt0 + my_tiles - 1; both halves run half_tiles loop steps
+    const int half_tiles = (nkt + KS - 1) / KS;
+    const int kt0 = kh * half_tiles;
+    const int my_tiles = nkt - kt0 < 0 ? 0 : (nkt - kt0 < half_tiles ? nkt - kt0 : half_tiles);
     // packed rows: the utterance starts at row row_off[n] of every head's [Tp, 64] block; query blocks past its end do
     // not exist (in the padded layout they are computed like the reference computes them: the rows feed later kernels)
     constexpr bool packed = PACKED;
@@ -111,7 +124,7 @@ __global__ __launch_bounds__(WAVES * 64, AMX_ATTN_OCC) void attn_kernel(const At
             for (int j = 0; j < PPW; ++j) {
                 const int piece = wave + WAVES * j;
                 const uint32_t so = (uint32_t)kt * TILE + pl * plane_b + piece * 1024;
-                unsigned char* dst = smem + st * STAGE + pl * 2 * TILE + piece * 1024;
+                unsigned char* dst = ring + st * STAGE + pl * 2 * TILE + piece * 1024;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_ptr_t)dst, 16, voff_k, so, 0, 0);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lds_ptr_t)(dst + TILE), 16, voff_v, so, 0, 0);
             }
@@ -136,7 +149,7 @@ __global__ __launch_bounds__(WAVES * 64, AMX_ATTN_OCC) void attn_kernel(const At
     for (int r = 0; r < 16; ++r) { O[0][r] = 0.f; O[1][r] = 0.f; }
     float m_run = 0.f, l_run = 0.f;  // scores are kept relative to m_run; the first tile sets it
 
-    stage(0, 0);
+    if (my_tiles > 0) stage(kt0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
@@ -157,13 +170,16 @@ __global__ __launch_bounds__(WAVES * 64, AMX_ATTN_OCC) void attn_kernel(const At
 #else
 #define ATTN_STAMP(var, prev)
 #endif
-    auto tile = [&](int kt, auto stc) {
+    // `i`: loop step of this wave's half, tile kt0 + i (a half with fewer tiles than the other idles through its last step)
+    auto tile = [&](int i, auto stc) {
         constexpr int ST = decltype(stc)::value;
+        const int kt = kt0 + i;
 #ifdef AMX_ATTN_STAMP
         unsigned long long st_prev = stamp();
 #endif
-        if (kt + 1 < nkt) stage(kt + 1, ST ^ 1);
-        const unsigned char* sb = smem + ST * STAGE;
+        if (i + 1 < my_tiles) stage(kt + 1, ST ^ 1);
+        const unsigned char* sb = ring + ST * STAGE;
+        if (KS == 1 || i < my_tiles) {
 
         // ---- S^T = K . Q^T : X[c][r] = score(key = kb + 32c + (r&3) + 8(r>>2) + 4hh, query), log2 units ----
         f32x16 X[NC];
@@ -224,8 +240,8 @@ __global__ __launch_bounds__(WAVES * 64, AMX_ATTN_OCC) void attn_kernel(const At
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         // wave-uniform; both lane halves of a query see the same mx.  The first tile always takes its own maximum (m_run
         // starts at 0, not at the scores' level); afterwards the maximum only moves when a tile exceeds it by 2^THR.
-        if (kt == 0 || !__all(mx <= DEFER_THR)) {
-            const float d = kt == 0 ? mx : fmaxf(mx, 0.f);
+        if (i == 0 || !__all(mx <= DEFER_THR)) {
+            const float d = i == 0 ? mx : fmaxf(mx, 0.f);
             const float alpha = __builtin_amdgcn_exp2f(-d);
             m_run += d;
             l_run *= alpha;
@@ -303,15 +319,39 @@ __global__ __launch_bounds__(WAVES * 64, AMX_ATTN_OCC) void attn_kernel(const At
         // in flight across the barrier: one 32-query block in ~1000 launches came out with a few keys of the wrong tile
         // (4 x 60 s batches, tools/stress_repro.py).
         ATTN_STAMP(st_pv, st_prev)
+        }  // (KS == 2: a step beyond this half's tiles only keeps the barrier count)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         ATTN_STAMP(st_wait, st_prev)
         __builtin_amdgcn_s_barrier();
         ATTN_STAMP(st_bar, st_prev)
     };
 
-    for (int kt = 0; kt < nkt; kt += 2) {
-        tile(kt, std::integral_constant<int, 0>{});
-        if (kt + 1 < nkt) tile(kt + 1, std::integral_constant<int, 1>{});
+    for (int i = 0; i < half_tiles; i += 2) {
+        tile(i, std::integral_constant<int, 0>{});
+        if (i + 1 < half_tiles) tile(i + 1, std::integral_constant<int, 1>{});
+    }
+    if constexpr (KS == 2) {
+        // merge the two key halves: the second half hands (m_run, l_run, O) over through LDS (the ring is idle: every wave is
+        // behind the last tile barrier), the first half folds them in -- max of the maxima, both sides rescaled to it
+        float* patch = (float*)(smem + wave * (34 * 64 * 4));
+        if (kh == 1) {
+            patch[lane] = my_tiles > 0 ? m_run : -INFINITY;  // a half without tiles contributes nothing
+            patch[64 + lane] = l_run;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { patch[(2 + r) * 64 + lane] = O[0][r]; patch[(18 + r) * 64 + lane] = O[1][r]; }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kh == 1) return;
+        const float m1 = patch[lane], l1 = patch[64 + lane];
+        const float m = fmaxf(m_run, m1);
+        const float a0 = __builtin_amdgcn_exp2f(m_run - m), a1 = __builtin_amdgcn_exp2f(m1 - m);
+        l_run = l_run * a0 + l1 * a1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            O[0][r] = O[0][r] * a0 + patch[(2 + r) * 64 + lane] * a1;
+            O[1][r] = O[1][r] * a0 + patch[(18 + r) * 64 + lane] * a1;
+        }
     }
 
 #ifdef AMX_ATTN_STAMP
@@ -700,25 +740,25 @@ void launch_attn2(const AttnParams& p, int cus, hipStream_t stream) {
     else launch_attn2_layout<T, NT, false, WAVES, STAGES>(p, cus, stream);
 }
 
-template <typename T, int NT, int WAVES, int KT, bool PACKED>
+template <typename T, int NT, int WAVES, int KT, bool PACKED, int KS = 1>
 void launch_attn_layout(const AttnParams& p, hipStream_t stream) {
 #ifdef AMX_ATTN_ABL_ONE_WG  // developer ablation: pad the LDS request so that only one workgroup fits a CU
     constexpr int lds = 100 * 1024;
 #else
-    constexpr int lds = 2 * NT * 2 * KT * 128;
+    constexpr int lds = KS * 2 * NT * 2 * KT * 128;  // (KS == 2: at least the 4 x 8.5 KiB of the merge patches)
 #endif
     static OncePerDevice attr;
     if (attr.first())
-        (void)hipFuncSetAttribute((const void*)attn_kernel<T, NT, WAVES, KT, PACKED>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)attn_kernel<T, NT, WAVES, KT, PACKED, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const int qblocks = (p.T + WAVES * 32 - 1) / (WAVES * 32);
     dim3 grid((unsigned)(8 * ((p.N * p.H + 7) / 8) * qblocks));
-    hipLaunchKernelGGL((attn_kernel<T, NT, WAVES, KT, PACKED>), grid, dim3(WAVES * 64), lds, stream, p);
+    hipLaunchKernelGGL((attn_kernel<T, NT, WAVES, KT, PACKED, KS>), grid, dim3(WAVES * KS * 64), lds, stream, p);
 }
 
-template <typename T, int NT, int WAVES, int KT>
+template <typename T, int NT, int WAVES, int KT, int KS = 1>
 void launch_attn(const AttnParams& p, hipStream_t stream) {
-    if (p.row_off) launch_attn_layout<T, NT, WAVES, KT, true>(p, stream);
-    else launch_attn_layout<T, NT, WAVES, KT, false>(p, stream);
+    if (p.row_off) launch_attn_layout<T, NT, WAVES, KT, true, KS>(p, stream);
+    else launch_attn_layout<T, NT, WAVES, KT, false, KS>(p, stream);
 }
 
 }  // namespace
@@ -749,7 +789,14 @@ void launch_attn_any(const AttnParams& p, hipStream_t stream) {
         }
     }
     const bool small = force ? force == 4 : wg8 * 2 <= cus;
-    if (small) launch_attn<T, NT, 4, 64>(p, stream);
+    // ... and when even the 128-query workgroups are at most one per CU, the key tiles of a query block are split over two wave
+    // groups (KS = 2): two waves per SIMD instead of one, half the serial key loop (AMX_ATTN_KSPLIT=0: developer A/B switch)
+    static const bool no_ksplit = getenv("AMX_ATTN_KSPLIT") && atoi(getenv("AMX_ATTN_KSPLIT")) == 0;
+    const int64_t wg4 = (int64_t)p.N * p.H * ((p.T + 127) / 128);
+    // (tools/attn_bench.hip, per launch: 4 x 10 s 23.0 -> 21.2 us, 1 x 10 s 19.2 -> 17.4, 2 x 20 s 38.7 -> 34.4; 1 x 3 s -- three key
+    // tiles -- 10.3 -> 10.9: from six tiles on)
+    if (small && !no_ksplit && !force && wg4 <= cus && p.T >= 384) launch_attn<T, NT, 4, 64, 2>(p, stream);
+    else if (small) launch_attn<T, NT, 4, 64>(p, stream);
     else launch_attn<T, NT, 8, 64>(p, stream);
 }
 

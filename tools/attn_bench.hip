@@ -51,18 +51,21 @@ int main(int argc, char** argv) {
     // per wave): outputs compared element by element (different softmax block sizes: close, not bitwise), then timed
     const size_t out_elems = (size_t)2 * N * T * H * 64;
     std::vector<unsigned short> o1(out_elems), o2(out_elems);
-    CK(hipMemset(out, 0, out_elems * 2));
-    launch_attn<f16, 2, 8, 64>(p, 0);
-    CK(hipDeviceSynchronize());
-    CK(hipMemcpy(o1.data(), out, out_elems * 2, hipMemcpyDeviceToHost));
-    CK(hipMemset(out, 0, out_elems * 2));
     const int v2_waves = getenv("ATTN2_WAVES") ? atoi(getenv("ATTN2_WAVES")) : 8;
+    const int base_waves = getenv("ATTN_BASE_WAVES") ? atoi(getenv("ATTN_BASE_WAVES")) : 8;  // 4: the short-batch form of attn_kernel
+    auto run1 = [&]() { if (base_waves == 4) launch_attn<f16, 2, 4, 64>(p, 0); else launch_attn<f16, 2, 8, 64>(p, 0); };
     auto run2 = [&]() {
-        if (v2_waves == 4) launch_attn2<f16, 2, 4, 2>(p, 256, 0);
+        if (v2_waves == 2) launch_attn<f16, 2, 4, 64, 2>(p, 0);  // attn_kernel with the key tiles split over two wave groups
+        else if (v2_waves == 4) launch_attn2<f16, 2, 4, 2>(p, 256, 0);
         else if (v2_waves == 3) launch_attn4<f16, 2>(p, 256, 0);
         else if (v2_waves == 5) launch_attn3<f16, 2>(p, 256, 0);
         else launch_attn2<f16, 2, 8, 4>(p, 256, 0);
     };
+    CK(hipMemset(out, 0, out_elems * 2));
+    run1();
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(o1.data(), out, out_elems * 2, hipMemcpyDeviceToHost));
+    CK(hipMemset(out, 0, out_elems * 2));
     run2();
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(o2.data(), out, out_elems * 2, hipMemcpyDeviceToHost));
@@ -83,15 +86,15 @@ int main(int argc, char** argv) {
         printf("attn2 vs attn: max |difference| %.3e (largest output %.3f)\n", worst, scale);
     }
     for (int variant = 0; variant < 2; ++variant) {
-        for (int i = 0; i < 3; ++i) { if (variant) run2(); else launch_attn<f16, 2, 8, 64>(p, 0); }
+        for (int i = 0; i < 3; ++i) { if (variant) run2(); else run1(); }
         CK(hipDeviceSynchronize());
         hipEventRecord(a, 0);
-        for (int i = 0; i < reps; ++i) { if (variant) run2(); else launch_attn<f16, 2, 8, 64>(p, 0); }
+        for (int i = 0; i < reps; ++i) { if (variant) run2(); else run1(); }
         hipEventRecord(b, 0);
         CK(hipEventSynchronize(b));
         float ms;
         hipEventElapsedTime(&ms, a, b);
-        printf("%s f16x3 N=%d T=%d: %.1f us per launch, %.0f TFLOP/s algorithmic (x3 issued: %.0f)\n", variant ? (v2_waves == 4 ? "attn2<4 waves, 2 slots>" : v2_waves == 5 ? "attn3 (ping-pong groups)" : v2_waves == 3 ? "attn4 (sub-blocks pipelined)" : "attn2<8 waves, 4 slots>") : "attn ", N, T,
+        printf("%s f16x3 N=%d T=%d: %.1f us per launch, %.0f TFLOP/s algorithmic (x3 issued: %.0f)\n", variant ? (v2_waves == 2 ? "attn<4 waves, key split 2>" : v2_waves == 4 ? "attn2<4 waves, 2 slots>" : v2_waves == 5 ? "attn3 (ping-pong groups)" : v2_waves == 3 ? "attn4 (sub-blocks pipelined)" : "attn2<8 waves, 4 slots>") : (base_waves == 4 ? "attn<4 waves>" : "attn<8 waves>"), N, T,
                ms * 1e3 / reps, flop / (ms / reps) / 1e9, 3 * flop / (ms / reps) / 1e9);
     }
 #ifdef AMX_ATTN2_REPORT
