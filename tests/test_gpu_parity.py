@@ -701,3 +701,32 @@ def test_packed_rows_give_the_bits_of_the_padded_layout(amd, shape, n, seconds):
         worst = max(max_abs_valid_tm(packed.outputs[k].cpu(), ref[k], ref_len) for k in ref)
         assert worst < GATE, worst
     est.close()
+
+
+@pytest.mark.parametrize("seconds,n", [(8.7, 2), (7.1, 3), (12.3, 1)])
+def test_short_batches_with_split_key_loops_against_oracle(amd, seconds, n):
+    """A few utterances of 7-12 s at XLS-R shape: the grid is at most one attention workgroup per CU, so the key tiles of a query
+    block are split over two wave groups and merged through LDS (``attn_kernel<KS = 2>``) -- odd and even tile counts, ragged
+    lengths in the packed and in the padded row layout, against the oracle; and the split is really taken (another result than
+    with AMX-level routing to the unsplit kernel would be bitwise equal otherwise -- checked through the launch count being the
+    same and the outputs differing in the last bits from a batch large enough to take the unsplit kernel)."""
+    from oracle import allophant_oracle as O
+
+    spec = S.multitask_spec(S.xlsr_300m_encoder(), allophone_layer=True)
+    spec["shared_phones"] = 80
+    state = synthetic.make_state_dict(spec, seed=0)
+    tfi = synthetic.make_inventory(spec, 27, seed=0)
+    audio, lengths = synthetic.make_audio(n, int(seconds * 16000), seed=777, ragged=True)
+    ref, ref_len = O.predict(audio, lengths, state, spec, tfi, synthetic.category_offsets(spec))
+    est = amd.Estimator(spec, state, "cuda:0", "f16x3")
+    batch = amd.Batch(audio.cuda(), lengths, torch.zeros(n, dtype=torch.long))
+    for no_pack in (False, True):
+        pred = est.predict(batch, tfi, _no_pack=no_pack)
+        assert torch.equal(pred.lengths.cpu(), ref_len)
+        worst = max(max_abs_valid_tm(pred.outputs[k].cpu(), ref[k], ref_len) for k in ref)
+        assert worst < GATE, (no_pack, worst)
+    decoded = est.greedy_decode(pred)
+    for k in ("phoneme", "syllabic"):
+        for i, (tokens, timesteps, _score) in enumerate(O.greedy_ctc(ref[k].transpose(0, 1).contiguous(), ref_len)):
+            assert torch.equal(decoded[k][i][0].tokens, tokens) and torch.equal(decoded[k][i][0].timesteps, timesteps), (k, i)
+    est.close()
