@@ -47,7 +47,7 @@ MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/f16 MFMA peak, /opt/skills/guides/MI355X
 HBM_PEAK_GBS = 8000.0
 MEASURED_MFMA_CEILING_TFLOPS = 2100.0  # 16x16x32 f16, two waves per SIMD (profiles/r02_mfma_only_ceiling.log)
 CONV0_PATTERN_STORE_GBS = 5660.0  # conv0's own store pattern without its arithmetic (tools/store_bw_probe.hip, profiles/r03_store_bw.log)
-TRAFFIC_FILES = ("r03il_traffic.json", "r03_traffic.json", "r02_traffic.json")  # newest first; written by tools/collect_profiles.py
+TRAFFIC_FILES = ("r04_traffic.json", "r04b_traffic.json", "r03il_traffic.json", "r03_traffic.json", "r02_traffic.json")  # newest first; written by tools/collect_profiles.py
 
 
 # BASELINE.json configs this file can time on one GPU (config 3 = config 2 under --gpus N; config 1 is CPU plumbing):

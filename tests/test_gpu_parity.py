@@ -706,10 +706,8 @@ def test_packed_rows_give_the_bits_of_the_padded_layout(amd, shape, n, seconds):
 @pytest.mark.parametrize("seconds,n", [(8.7, 2), (7.1, 3), (12.3, 1)])
 def test_short_batches_with_split_key_loops_against_oracle(amd, seconds, n):
     """A few utterances of 7-12 s at XLS-R shape: the grid is at most one attention workgroup per CU, so the key tiles of a query
-    block are split over two wave groups and merged through LDS (``attn_kernel<KS = 2>``) -- odd and even tile counts, ragged
-    lengths in the packed and in the padded row layout, against the oracle; and the split is really taken (another result than
-    with AMX-level routing to the unsplit kernel would be bitwise equal otherwise -- checked through the launch count being the
-    same and the outputs differing in the last bits from a batch large enough to take the unsplit kernel)."""
+    block are split over two wave groups and merged through LDS (``attn_kernel<KS = 2>``, taken from 384 frames on) -- odd and
+    even tile counts, ragged lengths in the packed and in the padded row layout, against the oracle."""
     from oracle import allophant_oracle as O
 
     spec = S.multitask_spec(S.xlsr_300m_encoder(), allophone_layer=True)
