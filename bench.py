@@ -399,6 +399,9 @@ def main():
         issue = 3 if planes == 2 else 1
         w = work_model(spec, n_local, length, planes)
         traffic, traffic_source = load_traffic(precision)
+        if args.config != 2 or args.utterances != CONFIG_PRESETS[2][0] or args.seconds != CONFIG_PRESETS[2][1] or world != 1:
+            # the committed PMC passes are those of config 2 on one GPU: another workload has other launches
+            traffic, traffic_source = None, "the committed PMC passes (profiles/) are those of BASELINE config 2 on one GPU: not reported for this workload"
         traffic = traffic or {}  # {} when no PMC pass of THESE kernel sources is committed: every traffic field is null
 
         def rate(flops, cls):
