@@ -59,8 +59,19 @@ CONFIG_PRESETS = {
 }
 
 
-def build_spec(hierarchical=False):
+def build_encoder(name):
+    """`xlsr` (default: every released Allophant checkpoint), or the group-norm / post-LN family the reference also accepts as
+    `model_id` (acoustic_model.py:775-826): `w2v2-base` (768 / 12 / 12 / 3072), `w2v2-large` (1024 / 24 / 16 / 4096)."""
+    if name == "w2v2-base":
+        return S.wav2vec2_base_encoder()
     encoder = S.xlsr_300m_encoder()
+    if name == "w2v2-large":
+        encoder.update(feat_extract_norm="group", conv_bias=False, stable_layer_norm=False, use_attention_mask=False)
+    return encoder
+
+
+def build_spec(hierarchical=False, encoder_name="xlsr"):
+    encoder = build_encoder(encoder_name)
     spec = S.hierarchical_spec(encoder, allophone_layer=True) if hierarchical else S.multitask_spec(encoder, allophone_layer=True)
     spec["shared_phones"] = 80
     return spec
@@ -92,7 +103,7 @@ def work_model(spec, n, length, planes):
         io = n * ts[i] * C * b16 + C * k * b16 + m * C * b16  # input planes once (overlapping windows), weights, output planes
         if i == last_conv:
             tail_flops, tail_bytes = flops, io
-        elif C == 512 and m >= 1024 and k % (128 // planes) == 0:
+        elif C == 512 and m >= 1024 and k % (128 // planes) == 0 and spec.get("feat_extract_norm", "layer") == "layer":
             ln_flops += flops
             ln_bytes += io
             ln_launches += 1
@@ -287,6 +298,9 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIG_PRESETS),
                     help="BASELINE.json config to time on one GPU: 2 (default, the configuration `metric` is quoted on; config 3 "
                          "under --gpus N), 4 (hierarchical, 64 x 5 s) or 5 (8 x 60 s, 200 phones)")
+    ap.add_argument("--encoder", default="xlsr", choices=["xlsr", "w2v2-base", "w2v2-large"],
+                    help="wav2vec 2.0 shape and variant: xlsr (default; `metric` is quoted on it) or the group-norm / post-LN family "
+                         "(informational lines: other work per frame)")
     ap.add_argument("--utterances", type=int, default=None, help="utterances of the (global) batch (default: the config's)")
     ap.add_argument("--seconds", type=float, default=None)
     ap.add_argument("--phones", type=int, default=None)
@@ -340,7 +354,7 @@ def main():
     from allophant_amd import parallel
     from allophant_amd.estimator import Batch, Estimator
 
-    spec = build_spec(hierarchical=preset[3])
+    spec = build_spec(hierarchical=preset[3], encoder_name=args.encoder)
     state = synthetic.make_state_dict(spec, seed=0)
     tfi = synthetic.make_inventory(spec, args.phones, seed=0)
     length = int(args.seconds * 16000)
@@ -399,7 +413,7 @@ def main():
         issue = 3 if planes == 2 else 1
         w = work_model(spec, n_local, length, planes)
         traffic, traffic_source = load_traffic(precision)
-        if args.config != 2 or args.utterances != CONFIG_PRESETS[2][0] or args.seconds != CONFIG_PRESETS[2][1] or world != 1:
+        if args.config != 2 or args.utterances != CONFIG_PRESETS[2][0] or args.seconds != CONFIG_PRESETS[2][1] or world != 1 or args.encoder != "xlsr":
             # the committed PMC passes are those of config 2 on one GPU: another workload has other launches
             traffic, traffic_source = None, "the committed PMC passes (profiles/) are those of BASELINE config 2 on one GPU: not reported for this workload"
         traffic = traffic or {}  # {} when no PMC pass of THESE kernel sources is committed: every traffic field is null
@@ -508,8 +522,9 @@ def main():
         graph_name = ("hierarchical checkpoint schema (36 attribute heads; the composed phoneme head reads cat(OUTPUT, softmax of every "
                       "attribute head)" if preset[3] else "multitask checkpoint schema (36 attribute heads + composed phoneme head")
         result = {
-            "metric": "encoder frames/sec (whole node), 10s x 32 utterances @16kHz" if args.config == 2 else
-                      f"encoder frames/sec (whole node), {args.seconds:g}s x {n_global} utterances @16kHz (BASELINE config {args.config})",
+            "metric": "encoder frames/sec (whole node), 10s x 32 utterances @16kHz" if args.config == 2 and args.encoder == "xlsr" else
+                      f"encoder frames/sec (whole node), {args.seconds:g}s x {n_global} utterances @16kHz (BASELINE config {args.config}"
+                      + ("" if args.encoder == "xlsr" else f", {args.encoder} encoder") + ")",
             "value": frames_global * args.steps / elapsed,
             "unit": "frames/s",
             "n_gpus": world,
@@ -531,6 +546,7 @@ def main():
                 "parallelism": f"dp{world} (contiguous utterance shards, no data-path collective; one RCCL gather of log-probs + frame "
                                f"lengths to rank 0 per step, overlapped with the next step)" if world > 1 else "single GPU",
                 "precision_mode": args.precision,
+                "encoder": args.encoder,
             },
             "roofline": roofline,
             "kernels": kernel_table(timing, args.steps),
