@@ -240,3 +240,26 @@ def test_checkpoint_model_id_selects_the_wav2vec2_variant():
     assert (cfg.feat_extract_norm, cfg.conv_bias, cfg.stable_layer_norm, cfg.use_attention_mask) == (lib.NORM_GROUP, 0, 0, 0)
     cfg, _ = _spec_to_structs(S.baseline_spec(S.tiny_encoder(1), 7), "f16x3")
     assert (cfg.feat_extract_norm, cfg.conv_bias, cfg.stable_layer_norm, cfg.use_attention_mask) == (lib.NORM_LAYER, 1, 1, 1)
+
+
+def test_bench_work_model_matches_the_survey_accounting():
+    """`bench.py`'s roofline accounting (algorithmic FLOPs per step, the figure `roofline.achieved` is computed from) against the
+    per-config totals of SURVEY.md Appendix D: 12.309 / 11.899 / 24.392 TFLOP per batch for configs 2 / 4 / 5, attention 0.783 /
+    0.390 / 7.073, conv stage 1.570 (config 2); and the routing of the products to kernel classes for both wav2vec 2.0 families."""
+    import bench
+
+    expected = {2: (12.309, 0.783, 499, 98, 5), 4: (11.899, 0.390, 249, 97, 5), 5: (24.392, 7.073, 2999, 98, 5)}
+    for number, (utterances, seconds, _phones, hierarchical) in bench.CONFIG_PRESETS.items():
+        w = bench.work_model(bench.build_spec(hierarchical), utterances, int(seconds * 16000), 2)
+        total, attention, frames, pp_launches, ln_launches = expected[number]
+        assert abs(w["total"] / 1e12 - total) < 0.01, (number, w["total"])
+        assert abs(w["attention"] / 1e12 - attention) < 0.001
+        assert w["frames_per_utt"] == frames
+        assert (w["gemm_pp_launches"], w["gemm_ln_launches"]) == (pp_launches, ln_launches), number
+    w = bench.work_model(bench.build_spec(False), 32, 160000, 2)
+    assert abs((w["conv0"] + w["gemm_ln"] + w["conv_tail"]) / 1e12 - 1.570) < 0.001
+    # the group-norm family has no fused conv + LayerNorm kernel: conv layers 1-5 are ping-pong products with a GELU epilogue
+    base = bench.work_model(bench.build_spec(False, "w2v2-base"), 32, 160000, 2)
+    assert base["gemm_ln_launches"] == 0 and base["gemm_pp_launches"] == 5 + 1 + 4 * 12 + 1
+    large = bench.work_model(bench.build_spec(False, "w2v2-large"), 32, 160000, 2)
+    assert large["gemm_ln_launches"] == 0 and abs(large["total"] - w["total"]) < 1e9
