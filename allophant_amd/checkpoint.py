@@ -134,6 +134,57 @@ def indexer_from_checkpoint(checkpoint: Dict[str, Any]):
     return table, training
 
 
+_EXTRACTOR = "_acoustic_model._model.feature_extractor.conv_layers."
+_ENCODER = "_acoustic_model._model.encoder."
+
+
+def check_encoder_against_state(encoder: Dict[str, Any], state: Dict[str, torch.Tensor], source: str) -> None:
+    """Cross-checks an encoder description (a ``MODEL_ID_ENCODERS`` entry is written from memory) against what the weights
+    themselves say: a wrong ``conv_bias`` would silently drop the biases, a wrong ``feat_extract_norm`` the norms.  Checked:
+    conv biases, the per-layer conv norms, layer and conv counts, hidden / ffn / conv widths and kernels.
+    ``stable_layer_norm`` and ``use_attention_mask`` leave NO trace in the weights (both encoder variants own the same
+    tensors; the mask is a preprocessor setting) -- they cannot be verified here and rest on the table alone."""
+    def has(key: str) -> bool:
+        return key in state
+
+    problems: List[str] = []
+    if not has(_EXTRACTOR + "0.conv.weight"):
+        return  # not a wav2vec 2.0 state dict of the reference's naming: amx_create reports what is missing
+    bias = has(_EXTRACTOR + "0.conv.bias")
+    if bias != bool(encoder.get("conv_bias", True)):
+        problems.append(f"conv_bias={encoder.get('conv_bias', True)} but the state dict "
+                        f"{'holds' if bias else 'has no'} conv_layers.0.conv.bias")
+    later_norm = has(_EXTRACTOR + "1.layer_norm.weight")
+    norm = "layer" if later_norm else "group"
+    if norm != encoder.get("feat_extract_norm", "layer"):
+        problems.append(f"feat_extract_norm={encoder.get('feat_extract_norm', 'layer')!r} but the state dict "
+                        f"{'holds' if later_norm else 'has no'} conv_layers.1.layer_norm (= {norm!r})")
+    n_conv = 0
+    while has(f"{_EXTRACTOR}{n_conv}.conv.weight"):
+        n_conv += 1
+    if n_conv != len(encoder["conv_kernel"]):
+        problems.append(f"{len(encoder['conv_kernel'])} conv layers described, {n_conv} in the state dict")
+    else:
+        for i in range(n_conv):
+            shape = tuple(state[f"{_EXTRACTOR}{i}.conv.weight"].shape)
+            if shape[0] != encoder["conv_dim"] or shape[2] != encoder["conv_kernel"][i]:
+                problems.append(f"conv layer {i}: weight {shape}, described as {encoder['conv_dim']} channels, kernel "
+                                f"{encoder['conv_kernel'][i]}")
+    layers = 0
+    while has(f"{_ENCODER}layers.{layers}.attention.q_proj.weight"):
+        layers += 1
+    if layers and layers != encoder["layers"]:
+        problems.append(f"{encoder['layers']} encoder layers described, {layers} in the state dict")
+    if layers:
+        q = tuple(state[f"{_ENCODER}layers.0.attention.q_proj.weight"].shape)
+        f = tuple(state[f"{_ENCODER}layers.0.feed_forward.intermediate_dense.weight"].shape)
+        if q[0] != encoder["hidden"] or f[0] != encoder["ffn"]:
+            problems.append(f"hidden / ffn described as {encoder['hidden']} / {encoder['ffn']}, the weights are {q[0]} / {f[0]}")
+    if problems:
+        raise ValueError(f"the encoder description from {source} does not match the checkpoint's weights: " + "; ".join(problems)
+                         + ".  Pass the right description in additional['amx_encoder'].")
+
+
 def spec_from_checkpoint(checkpoint: Dict[str, Any]) -> Dict[str, Any]:
     for field in ("config", "attribute_graph", "model_state", "sample_rate", "feature_size"):
         if field not in checkpoint:
@@ -148,8 +199,10 @@ def spec_from_checkpoint(checkpoint: Dict[str, Any]) -> Dict[str, Any]:
     acoustic = nn_config.get("acoustic_model", {})
     if "amx_encoder" in additional:
         encoder = dict(additional["amx_encoder"])
+        check_encoder_against_state(encoder, checkpoint["model_state"], "additional['amx_encoder']")
     elif acoustic.get("model_id") in MODEL_ID_ENCODERS:
         encoder = MODEL_ID_ENCODERS[acoustic["model_id"]]()
+        check_encoder_against_state(encoder, checkpoint["model_state"], f"MODEL_ID_ENCODERS[{acoustic['model_id']!r}]")
     else:
         raise ValueError(f"Unsupported model type: {acoustic.get('type')!r} / {acoustic.get('model_id')!r}")
     projection = nn_config["projection"]

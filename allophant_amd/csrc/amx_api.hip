@@ -155,6 +155,34 @@ struct amx_handle_s {
     std::vector<hipEvent_t> event_pool;
     bool timing = false;
     hipStream_t timing_stream = nullptr;
+    // HIP graphs of whole forward passes (region "enqueue" of amx_forward: every memset, kernel and device copy of a pass;
+    // the small pinned H2D uploads stay eager in front of it).  A pass is captured when the same key -- buffers, geometry,
+    // lengths, flags, inventory, workspace generation -- recurs among the last few passes, and replayed while it recurs: one
+    // hipGraphLaunch instead of ~185 launches.  Cached LRU; dropped when a workspace buffer moves.
+    struct GraphEntry {
+        std::vector<int64_t> key;
+        hipGraphExec_t exec = nullptr;
+        uint64_t last_use = 0;
+    };
+    static constexpr int GRAPH_CAP = 8;
+    std::vector<GraphEntry> graphs;
+    std::vector<std::vector<int64_t>> graph_seen;  // keys of the last few eager passes (a caller that alternates between two
+                                                   // output buffers -- an overlapped gather holds one -- repeats with period 2)
+    static constexpr int GRAPH_SEEN = 4;
+    hipStream_t capture_stream = nullptr;  // capture never runs on the caller's stream (which may be the null stream)
+    bool graph_broken = false;             // a capture failed once: stay eager
+    uint64_t ws_gen = 0, graph_clock = 0;
+    int64_t graph_captures = 0, graph_replays = 0;
+    // range report (AMX_ERANGE) without a host synchronisation: every pass copies its non-finite frame count into a pinned
+    // slot behind itself; the NEXT amx_forward / amx_synchronize reads the slots whose event has completed
+    struct RangeSlot {
+        int* host = nullptr;
+        hipEvent_t ev = nullptr;
+        bool pending = false, cont = false;
+    };
+    static constexpr int RANGE_SLOTS = 8;
+    RangeSlot range[RANGE_SLOTS];
+    int range_next = 0;
     // last forward geometry
     int last_N = 0;
     bool qkv_dirty = false;
@@ -207,6 +235,7 @@ int ws_get(amx_handle h, const char* name, size_t bytes, void** out, bool zero_o
         if (hipMalloc(&w.p, want) != hipSuccess) return fail(h, AMX_ENOMEM, std::string("workspace allocation failed: ") + name);
         w.bytes = want;
         h->ws_bytes += (int64_t)want;
+        ++h->ws_gen;  // a buffer moved: every captured graph holds stale pointers
         if (zero_on_grow) HIPCHK(h, hipMemset(w.p, 0, want));
     }
     *out = w.p;
@@ -281,6 +310,7 @@ int evaluation_order(const std::vector<amx_class_desc>& cls, std::vector<int>& o
 }  // namespace
 
 static void free_inventory(amx_handle_s::Inventory& e);
+static void drop_graphs(amx_handle h);
 static int install_inventory(amx_handle h, std::vector<int64_t>&& key, const std::vector<int64_t>& idx, int P1, int features,
                              hipStream_t s);
 
@@ -323,7 +353,7 @@ static int pack_linear(amx_handle h, const TensorMap& tm, const std::string& key
 
 // power of two that puts the largest |w * pre| of the listed tensors into [4096, 8192); 1 for empty / zero / non-finite data
 static bool pack_scale_off() {  // AMX_NO_PACK_SCALE=1: developer A/B switch (unscaled planes, as before round 3)
-    static const bool off = getenv("AMX_NO_PACK_SCALE") && atoi(getenv("AMX_NO_PACK_SCALE")) != 0;
+    static const bool off = dev_switch("AMX_NO_PACK_SCALE");
     return off;
 }
 static float pow2_for(float m) {
@@ -365,6 +395,11 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
         return fail(nullptr, AMX_EINVAL, "hidden and conv_dim must be multiples of 8 and <= 1024");
     if (cfg->conv_dim >= 64 && cfg->conv_dim % 64) return fail(nullptr, AMX_EINVAL, "conv_dim must be < 64 or a multiple of 64");
     if (cfg->conv_kernel[0] > 16) return fail(nullptr, AMX_EINVAL, "first conv kernel must be <= 16");
+    for (int i = 0; i < cfg->n_conv; ++i)
+        if (cfg->conv_kernel[i] < 1 || cfg->conv_stride[i] < 1) return fail(nullptr, AMX_EINVAL, "conv kernels and strides must be positive");
+    if (conv0_window_lds_bytes(cfg->conv_kernel[0], cfg->conv_stride[0], cfg->feat_extract_norm == AMX_NORM_GROUP) > 64 * 1024)
+        return fail(nullptr, AMX_EINVAL, "first conv stride too large for the LDS window of the conv-0 kernels (stride <= 16 with the "
+                                         "group-norm extractor, <= 127 otherwise)");
     if (cfg->hidden % cfg->pos_groups != 0 || (cfg->hidden / cfg->pos_groups) % 8 || cfg->hidden / cfg->pos_groups > 64)
         return fail(nullptr, AMX_EINVAL, "hidden / pos_groups must be a multiple of 8 and <= 64");
     if (cfg->ffn % 8) return fail(nullptr, AMX_EINVAL, "ffn must be a multiple of 8");
@@ -389,7 +424,7 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
     h->stable = cfg->stable_layer_norm != 0;
     h->masked = cfg->use_attention_mask != 0;
     {
-        static const bool plain = getenv("AMX_PLAIN_PLANES") && atoi(getenv("AMX_PLAIN_PLANES")) != 0;  // developer A/B switch
+        static const bool plain = dev_switch("AMX_PLAIN_PLANES");  // developer A/B switch
         h->il = h->NT > 1 && !plain && cfg->conv_dim % 32 == 0 && cfg->ffn % 32 == 0;
     }
     h->classes.assign(classes, classes + n_classes);
@@ -739,6 +774,12 @@ extern "C" int amx_destroy(amx_handle h) {
         if (h->h_tiles_pinned[i]) (void)hipHostFree(h->h_tiles_pinned[i]);
         if (h->pin_event[i]) (void)hipEventDestroy(h->pin_event[i]);
     }
+    drop_graphs(h);
+    if (h->capture_stream) (void)hipStreamDestroy(h->capture_stream);
+    for (auto& sl : h->range) {
+        if (sl.host) (void)hipHostFree(sl.host);
+        if (sl.ev) (void)hipEventDestroy(sl.ev);
+    }
     for (auto& sp : h->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto e : h->event_pool) (void)hipEventDestroy(e);
     delete h;
@@ -1003,13 +1044,83 @@ extern "C" int amx_output_layout(amx_handle h, int N, int64_t L, amx_output_desc
 // =================================================================================================================
 // forward
 // =================================================================================================================
+static void drop_graphs(amx_handle h) {
+    for (auto& g : h->graphs)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    h->graphs.clear();
+    h->graph_seen.clear();
+}
+
+// Range report of EARLIER forward passes: reads the pinned count of every pass whose trailing event has completed (`wait`:
+// of every pass issued -- the caller has just synchronised or accepts to).  Returns AMX_ERANGE when one of them counted valid
+// frames with non-finite logits; the report is consumed by the call that returns it.
+static int range_poll(amx_handle h, bool wait) {
+    int64_t total = 0;
+    int prev_count = 0;
+    bool have_prev = false;
+    for (int i = 0; i < amx_handle_s::RANGE_SLOTS; ++i) {
+        auto& sl = h->range[(h->range_next + i) % amx_handle_s::RANGE_SLOTS];  // oldest first
+        if (!sl.pending) continue;
+        if (wait) {
+            HIPCHK(h, hipEventSynchronize(sl.ev));
+        } else {
+            const hipError_t q = hipEventQuery(sl.ev);
+            if (q == hipErrorNotReady) break;  // passes complete in issue order on a stream: nothing later is ready either
+            if (q != hipSuccess) { (void)hipGetLastError(); break; }
+        }
+        sl.pending = false;
+        // the slices of one over-long batch (AMX_FLAG_CONTINUE) share a running count: only its last reading is a total
+        if (have_prev && !sl.cont) total += prev_count;
+        prev_count = *sl.host;
+        have_prev = true;
+    }
+    if (have_prev) total += prev_count;
+    if (total > 0)
+        return fail(h, AMX_ERANGE, std::to_string(total) + " valid frame(s) of an EARLIER forward pass hold non-finite logits: an activation left the "
+                                   "range of the 16-bit planes (fp16: |x| <= 65504) or the input was not finite; the outputs of that pass "
+                                   "are not usable.  The bf16 planes (precision bf16x3) have the range of fp32; AMX_FLAG_NO_RANGE_CHECK "
+                                   "turns this report off");
+    return AMX_OK;
+}
+
+// enqueues the count of the pass just issued on `s` into the next pinned slot
+static int range_record(amx_handle h, bool cont, hipStream_t s) {
+    auto& sl = h->range[h->range_next];
+    if (!sl.host) {
+        HIPCHK(h, hipHostMalloc((void**)&sl.host, 16));
+        HIPCHK(h, hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+    }
+    if (sl.pending) {
+        // RANGE_SLOTS passes ago and never polled since: fold its reading into the slot that follows instead of losing it
+        HIPCHK(h, hipEventSynchronize(sl.ev));
+        auto& next = h->range[(h->range_next + 1) % amx_handle_s::RANGE_SLOTS];
+        if (next.pending && !next.cont && *sl.host > 0) {
+            HIPCHK(h, hipEventSynchronize(next.ev));
+            *next.host += *sl.host;
+        }
+        sl.pending = false;
+    }
+    HIPCHK(h, hipMemcpyAsync(sl.host, h->nonfinite, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipEventRecord(sl.ev, s));
+    sl.pending = true;
+    sl.cont = cont;
+    h->range_next = (h->range_next + 1) % amx_handle_s::RANGE_SLOTS;
+    return AMX_OK;
+}
+
 extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* lengths, int N, int64_t L, float* out,
                            int64_t* out_lengths, uint32_t flags, void* stream_) {
     if (!h) return AMX_EINVAL;
     if (!audio || !lengths || !out) return fail(h, AMX_EINVAL, "null buffer");
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream_;
-    int rc = compute_layout(h, N, L);
+    int rc;
+    // Safe by default: the reference computes in fp32 and cannot overflow (estimator.py:1035-1046); the fp16 planes can.  A
+    // pass that produced non-finite logits on valid frames is reported -- AMX_ERANGE -- by the first amx_forward /
+    // amx_synchronize issued after it has completed; nothing of THIS call has been enqueued when that happens.  No host
+    // synchronisation: only passes whose trailing event has completed are read.
+    if (!(flags & AMX_FLAG_NO_RANGE_CHECK) && (rc = range_poll(h, false))) return rc;
+    rc = compute_layout(h, N, L);
     if (rc) return rc;
     const amx_config& c = h->cfg;
     const int NT = h->NT, prec = h->prec;
@@ -1103,7 +1214,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     // product never exceed CUs x 256 x 256 floats
     void* splitk = nullptr;
     constexpr size_t SPLITK_BYTES = (size_t)72 << 20;
-    static const bool no_splitk = getenv("AMX_NO_SPLITK") && atoi(getenv("AMX_NO_SPLITK")) != 0;  // developer A/B switch
+    static const bool no_splitk = dev_switch("AMX_NO_SPLITK");  // developer A/B switch
     if (!no_splitk) WS("splitk", SPLITK_BYTES, splitk);
     auto run_gemm = [&](int precision, GemmParams& g, hipStream_t stream) {
         g.splitk_ws = (float*)splitk;
@@ -1137,7 +1248,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     // the products pick the same kernels for the smaller row count, within rounding of the K-chunk order otherwise).  Used
     // when at least a tenth of the padded rows are padding (not under AMX_FLAG_KEEP_HIDDEN); AMX_FLAG_NO_PACK /
     // AMX_NO_PACKED_ROWS=1 keep the padded layout.
-    static const bool no_pack_env = getenv("AMX_NO_PACKED_ROWS") && atoi(getenv("AMX_NO_PACKED_ROWS")) != 0;
+    static const bool no_pack_env = dev_switch("AMX_NO_PACKED_ROWS");
     const bool any_hidden = keep;  // the debug capture wants every hidden state in the padded layout, padding included
     const int TpTot = round_up((int)Mp, 64) + 64;  // rows per head of the packed Q / K / V planes
     bool packed = !no_pack_env && !(flags & AMX_FLAG_NO_PACK) && !any_hidden && D % 4 == 0 && Mp * 10 <= M * 9 &&
@@ -1148,28 +1259,16 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     // Needs the window kernel (the grouped-GEMM form of the positional convolution addresses padded rows) and no time-layer
     // head (its attention walks (utterance, frame) pairs); otherwise the rows are packed after the positional convolution
     // and unpacked before the final LayerNorm, as in round 2.
-    static const bool no_window = getenv("AMX_NO_POSCONV_WINDOW") && atoi(getenv("AMX_NO_POSCONV_WINDOW")) != 0;  // developer A/B switch
-    static const bool late_pack = getenv("AMX_PACK_LATE") && atoi(getenv("AMX_PACK_LATE")) != 0;                  // developer A/B switch
+    static const bool no_window = dev_switch("AMX_NO_POSCONV_WINDOW");  // developer A/B switch
+    static const bool late_pack = dev_switch("AMX_PACK_LATE");          // developer A/B switch
     const bool window_ok = !no_window && posconv_window_eligible(D, c.pos_groups, c.pos_kernel, N, T, Tpad, (int64_t)N * Tpad * D);
     bool any_time_layer = false;
     for (auto& st : h->steps) any_time_layer |= st.time_heads > 0;
     // (the post-LN encoder has no LayerNorm pass between its last layer and the heads to unpack behind: it packs early or not at all)
     if (!h->stable && !(window_ok && !any_time_layer && !late_pack)) packed = false;
     const bool packed_early = packed && window_ok && !any_time_layer && !late_pack;
-    // K/V/Q padding rows [T, Tp) must stay finite: re-zero when the geometry changes
-    if (!packed && (h->last_N != N || h->last_T != T || h->qkv_dirty)) {
-        HIPCHK(h, hipMemsetAsync(qb, 0, qkv_bytes, s));
-        HIPCHK(h, hipMemsetAsync(kb, 0, qkv_bytes, s));
-        HIPCHK(h, hipMemsetAsync(vtb, 0, qkv_bytes, s));
-    }
     void* hpk = nullptr;
-    if (packed) {
-        WS("h_packed", (size_t)Mp * D * 4, hpk);
-        // rows [Mp, TpTot) of every head are read (never used) by the last key tile and query block: keep them finite
-        const size_t row_b = 64 * 2, tail = (size_t)(TpTot - Mp) * row_b, pitch = (size_t)TpTot * row_b;
-        for (void* buf : {qb, kb, vtb})  // the planes lie back to back: NT * H blocks of TpTot rows
-            HIPCHK(h, hipMemset2DAsync((char*)buf + (size_t)Mp * row_b, pitch, 0, tail, (size_t)NT * H, s));
-    }
+    if (packed) WS("h_packed", (size_t)Mp * D * 4, hpk);
     const float* d_audio = audio;
     float* d_out = out;
     const int64_t total = layout_total(h, N, T);
@@ -1239,6 +1338,88 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     HIPCHK(h, hipEventRecord(h->pin_event[slot], s));
     h->pin_busy[slot] = true;
 
+    // ---- the rest of the plan: every buffer and host-side table the pass needs exists before anything is enqueued, so that
+    // the enqueue region below issues nothing but memsets, kernels and device copies (which is what a HIP graph may hold) ----
+    void *gn_partial = nullptr, *gn_scale = nullptr, *gn_shift = nullptr;
+    if (h->gn) {
+        WS("gn_partial", conv0_groupnorm_partial_bytes(N, (int)Ts[1], C), gn_partial);
+        WS("gn_scale", (size_t)N * C * 4, gn_scale);
+        WS("gn_shift", (size_t)N * C * 4, gn_shift);
+    }
+    const bool stable = h->stable;
+    const int64_t Mh = packed_early ? Mp : M;  // rows of the final LayerNorm and of the classifier heads
+    // hidden_states[layers]: the final LayerNorm's fp32 rows; post-LN encoder: the stream as the last layer left it (kept in
+    // a buffer of its own only for the debug capture)
+    float* const hfin_rows = (stable || keep) ? (float*)hfin : (float*)(packed ? hpk : hbuf);
+    saved[c.layers] = hfin_rows;
+    const int E = c.embedding_size;
+    void *ebuf = nullptr, *cat = nullptr;
+    int kcat = 0;
+    for (auto& st : h->steps) kcat = std::max(kcat, st.direct_output ? 0 : st.Kpad);
+    const int Eld = round_up(E, kalign(h));  // row stride of the embedding planes (pad columns are never read: K = E)
+    if (E > 0) WS("e", (size_t)M * Eld * 2 * NT + PLANE_SLACK, ebuf);
+    if (kcat > 0) WS("cat", (size_t)M * kcat * 2 * NT + PLANE_SLACK, cat);
+    void *tl_x = nullptr, *tl_p = nullptr, *tl_qkv = nullptr;
+    {
+        int cmax = 0;
+        for (auto& st : h->steps)
+            if (st.time_heads > 0) {
+                cmax = std::max(cmax, st.Cpad);
+                if (time_attention_lds_bytes(T, st.rows / st.time_heads) > 160 * 1024)
+                    return fail(h, AMX_EINVAL, "utterance too long for the time-layer attention (frames + head_dim > 10240)");
+            }
+        if (cmax > 0) {
+            WS("tl_x", (size_t)M * cmax * 4, tl_x);
+            WS("tl_p", (size_t)M * cmax * 2 * NT + PLANE_SLACK, tl_p);
+            WS("tl_qkv", (size_t)M * cmax * 3 * 4, tl_qkv);
+        }
+    }
+    const bool blanks = c.dependency_blanks != 0;
+    for (auto& st : h->steps) {
+        if (st.direct_output) continue;
+        // concatenation recipe of a classifier with dependencies: source pointers / logit columns of this pass
+        for (size_t i = 0; i < st.parts.size(); ++i) {
+            int dep = st.part_dep[i];
+            if (dep < 0) {
+                st.parts[i].src = dep == AMX_DEP_OUTPUT ? hfin_rows : saved[-2 - dep];
+            } else {
+                st.parts[i].src_col = h->col[dep] + (blanks ? 0 : 1);
+                // a composed dependency has an inventory-dependent width; the classifier was trained on the training
+                // inventory, so the widths must agree
+                int w = h->width[dep] - (blanks ? 0 : 1);
+                if (w != st.parts[i].width)
+                    return fail(h, AMX_EINVAL, "inventory size does not match the input width of a dependent classifier");
+            }
+        }
+        if (st.parts_uploaded.size() != st.parts.size() ||
+            memcmp(st.parts_uploaded.data(), st.parts.data(), st.parts.size() * sizeof(ConcatPart)) != 0) {
+            // the recipe only changes with the workspace pointers or the inventory; st.parts is pageable host memory,
+            // so this (rare) upload completes before the call goes on.  A captured graph never holds it: parts_dev is
+            // read by the concat kernel, and a changed recipe comes with a changed workspace generation or inventory.
+            HIPCHK(h, hipMemcpyAsync(st.parts_dev, st.parts.data(), st.parts.size() * sizeof(ConcatPart), hipMemcpyHostToDevice, s));
+            HIPCHK(h, hipStreamSynchronize(s));
+            st.parts_uploaded = st.parts;
+        }
+    }
+    const bool needs_qkv_zero = !packed && (h->last_N != N || h->last_T != T || h->qkv_dirty);
+
+    // =============================================================================================================
+    // enqueue: the whole pass on stream `s` -- memsets, kernels, device-to-device copies only (eagerly on the caller's
+    // stream, or once on the capture stream when the pass is recorded into a HIP graph)
+    // =============================================================================================================
+    auto enqueue = [&](hipStream_t s) -> int {
+    // K/V/Q padding rows [T, Tp) must stay finite: re-zero when the geometry changes
+    if (needs_qkv_zero) {
+        HIPCHK(h, hipMemsetAsync(qb, 0, qkv_bytes, s));
+        HIPCHK(h, hipMemsetAsync(kb, 0, qkv_bytes, s));
+        HIPCHK(h, hipMemsetAsync(vtb, 0, qkv_bytes, s));
+    }
+    if (packed) {
+        // rows [Mp, TpTot) of every head are read (never used) by the last key tile and query block: keep them finite
+        const size_t row_b = 64 * 2, tail = (size_t)(TpTot - Mp) * row_b, pitch = (size_t)TpTot * row_b;
+        for (void* buf : {qb, kb, vtb})  // the planes lie back to back: NT * H blocks of TpTot rows
+            HIPCHK(h, hipMemset2DAsync((char*)buf + (size_t)Mp * row_b, pitch, 0, tail, (size_t)NT * H, s));
+    }
     // amx_check_finite reports on THIS forward pass; the later slices of one over-long batch (AMX_FLAG_CONTINUE) add up
     if (!(flags & AMX_FLAG_CONTINUE)) HIPCHK(h, hipMemsetAsync(h->nonfinite, 0, 4, s));
     // ---- input normalisation statistics + conv layer 0 (fused norm + conv + LN + GELU) ----
@@ -1246,10 +1427,6 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     if (h->gn) {
         // group-norm variant: GroupNorm statistics over ALL frames of the padded length (upstream normalises the padded batch
         // tensor), then conv + affine + GELU; frame blocks in an utterance's padding may still be skipped in the second pass
-        void *gn_partial, *gn_scale, *gn_shift;
-        WS("gn_partial", conv0_groupnorm_partial_bytes(N, (int)Ts[1], C), gn_partial);
-        WS("gn_scale", (size_t)N * C * 4, gn_scale);
-        WS("gn_shift", (size_t)N * C * 4, gn_shift);
         Timed t_(h, AMX_KC_CONV0);
         launch_conv0_groupnorm(prec, d_audio, (const int64_t*)d_len, (const float*)d_stats, N, L, (int)Ts[1], C, c.conv_kernel[0],
                                c.conv_stride[0], h->c0_w, h->conv_b[0], h->conv_g[0], h->conv_be[0], 1e-5f, c.do_normalize,
@@ -1307,8 +1484,8 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             f.act = 1; f.ln_gamma = h->conv_g[i]; f.ln_beta = h->conv_be[i]; f.ln_eps = 1e-5f;
             f.out_p = other; f.out_plane = out_plane; f.ldp = C;
             // AMX_NO_FUSED_CONV_LN=1: developer A/B switch (separate fp32 GEMM output + row kernel)
-            const char* no_fuse = getenv("AMX_NO_FUSED_CONV_LN");
-            if (!(no_fuse && no_fuse[0] == '1') && gemm_fuses_ln(prec, f)) {
+            static const bool no_fuse = dev_switch("AMX_NO_FUSED_CONV_LN");
+            if (!no_fuse && gemm_fuses_ln(prec, f)) {
                 if (h->conv_w_tm[i] && gemm_ln_tap_minor_slice(prec, f) == h->conv_tm_slice) {
                     // tap-minor K order: the input row two output rows share is fetched in adjacent slices (an L2 hit)
                     f.W = h->conv_w_tm[i];
@@ -1395,7 +1572,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     // A residual product that launch_gemm cuts into K chunks (short batches) leaves its fix-up -- slab sum + bias + residual
     // -> h -- to the LayerNorm that follows it: one kernel instead of the fix-up and a LayerNorm pass that re-reads h
     // (AMX_NO_FUSED_FIXUP=1: developer A/B switch).
-    static const bool no_fused_fixup = getenv("AMX_NO_FUSED_FIXUP") && atoi(getenv("AMX_NO_FUSED_FIXUP")) != 0;
+    static const bool no_fused_fixup = dev_switch("AMX_NO_FUSED_FIXUP");
     struct { bool on = false; GemmParams g; int splits = 0; } pending;
     auto residual_gemm = [&](GemmParams& g, bool may_defer) {
         g.splitk_ws = (float*)splitk;
@@ -1419,7 +1596,6 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             launch_rownorm(prec, (const float*)hbuf, D, rows, D, gamma, beta, 0, nullptr, nullptr, c.eps, 0.f, xp, plane, D, out_ln, D, s);
         }
     };
-    const bool stable = h->stable;
     // post-LN encoder (Wav2Vec2Encoder): h = LayerNorm(h + pos_conv(h)) first; every layer is h = LN1(h + attention(h)),
     // h = LN2(h + FFN(h)); hidden_states[layers] is the last layer's output as it is.  The LayerNorm passes write the fp32
     // rows back in place (the residual stream IS the normalised tensor) next to the planes the products read.
@@ -1500,65 +1676,18 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         { Timed t_(h, AMX_KC_OTHER); launch_pack_rows((const float*)hpad, (float*)hpk, (const int*)d_rowoff, (const int*)d_frames, N, T, D, true, s); }
         hbuf = hpad;
     }
-    const int64_t Mh = packed_early ? Mp : M;  // rows of the final LayerNorm and of the classifier heads
     if (stable) {
         stream_norm(h->fln_g, h->fln_b, Mh, pln(h, Mh * D), (float*)hfin);
-    } else {
-        // post-LN: hidden_states[layers] = the stream as the last layer left it; its planes are in xp already
-        if (keep) HIPCHK(h, hipMemcpyAsync(hfin, hbuf, (size_t)Mh * D * 4, hipMemcpyDeviceToDevice, s));
-        else hfin = hbuf;
-        saved[c.layers] = (float*)hfin;
+    } else if (keep) {
+        // post-LN: hidden_states[layers] = the stream as the last layer left it (hfin_rows); its planes are in xp already
+        HIPCHK(h, hipMemcpyAsync(hfin, hbuf, (size_t)Mh * D * 4, hipMemcpyDeviceToDevice, s));
     }
 
     // ---- hierarchical projection ----
-    const int E = c.embedding_size;
-    void *ebuf = nullptr, *cat = nullptr;
-    int kcat = 0;
-    for (auto& st : h->steps) kcat = std::max(kcat, st.direct_output ? 0 : st.Kpad);
-    const int Eld = round_up(E, kalign(h));  // row stride of the embedding planes (pad columns are never read: K = E)
-    if (E > 0) WS("e", (size_t)M * Eld * 2 * NT + PLANE_SLACK, ebuf);
-    if (kcat > 0) WS("cat", (size_t)M * kcat * 2 * NT + PLANE_SLACK, cat);
-    void *tl_x = nullptr, *tl_p = nullptr, *tl_qkv = nullptr;
-    {
-        int cmax = 0;
-        for (auto& st : h->steps)
-            if (st.time_heads > 0) {
-                cmax = std::max(cmax, st.Cpad);
-                if (time_attention_lds_bytes(T, st.rows / st.time_heads) > 160 * 1024)
-                    return fail(h, AMX_EINVAL, "utterance too long for the time-layer attention (frames + head_dim > 10240)");
-            }
-        if (cmax > 0) {
-            WS("tl_x", (size_t)M * cmax * 4, tl_x);
-            WS("tl_p", (size_t)M * cmax * 2 * NT + PLANE_SLACK, tl_p);
-            WS("tl_qkv", (size_t)M * cmax * 3 * 4, tl_qkv);
-        }
-    }
-    const bool blanks = c.dependency_blanks != 0;
     for (auto& st : h->steps) {
         const void* A = xp;
         int64_t a_plane = pln(h, Mh * D), lda = D;
         if (!st.direct_output) {
-            for (size_t i = 0; i < st.parts.size(); ++i) {
-                int dep = st.part_dep[i];
-                if (dep < 0) {
-                    st.parts[i].src = dep == AMX_DEP_OUTPUT ? (const float*)hfin : saved[-2 - dep];
-                } else {
-                    st.parts[i].src_col = h->col[dep] + (blanks ? 0 : 1);
-                    // a composed dependency has an inventory-dependent width; the classifier was trained on the training
-                    // inventory, so the widths must agree
-                    int w = h->width[dep] - (blanks ? 0 : 1);
-                    if (w != st.parts[i].width)
-                        return fail(h, AMX_EINVAL, "inventory size does not match the input width of a dependent classifier");
-                }
-            }
-            if (st.parts_uploaded.size() != st.parts.size() ||
-                memcmp(st.parts_uploaded.data(), st.parts.data(), st.parts.size() * sizeof(ConcatPart)) != 0) {
-                // the recipe only changes with the workspace pointers or the inventory; st.parts is pageable host memory,
-                // so this (rare) upload completes before the call goes on
-                HIPCHK(h, hipMemcpyAsync(st.parts_dev, st.parts.data(), st.parts.size() * sizeof(ConcatPart), hipMemcpyHostToDevice, s));
-                HIPCHK(h, hipStreamSynchronize(s));
-                st.parts_uploaded = st.parts;
-            }
             { Timed t_(h, AMX_KC_OTHER); launch_concat(prec, st.parts_dev, (int)st.parts.size(), (const float*)logits, h->ld_logits, Mh, cat,
                           pln(h, Mh * st.Kpad), st.Kpad, st.Kpad, s); }
             A = cat; a_plane = pln(h, Mh * st.Kpad); lda = st.Kpad;
@@ -1611,6 +1740,81 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
                           (const int*)d_frames, (flags & AMX_FLAG_RAW_LOGITS) ? 0 : 1, d_out, h->nonfinite,
                           packed_early ? (const int*)d_rowoff : nullptr, s); }
     HIPCHK(h, hipGetLastError());
+    return AMX_OK;
+    };  // enqueue
+
+    // ---- run the pass: replay its graph, record one, or enqueue it eagerly ----
+    const bool graph_ok = !h->graph_broken && !(flags & (AMX_FLAG_NO_GRAPH | AMX_FLAG_TIMING | AMX_FLAG_KEEP_HIDDEN));
+    bool done = false;
+    if (graph_ok) {
+        std::vector<int64_t> key;
+        key.reserve(10 + (size_t)N);
+        key.insert(key.end(), {(int64_t)(intptr_t)d_audio, (int64_t)(intptr_t)d_out, (int64_t)N, L, (int64_t)flags, (int64_t)needs_qkv_zero,
+                               (int64_t)h->inv, (int64_t)h->inventories[h->inv].generation, (int64_t)h->ws_gen});
+        key.insert(key.end(), lengths, lengths + N);
+        if (!h->graphs.empty() && h->graphs.front().key.size() >= 9 && h->graphs.front().key[8] != (int64_t)h->ws_gen) {
+            // a workspace buffer moved since these were recorded (ws_get synchronised the device before freeing it)
+            drop_graphs(h);
+        }
+        for (auto& g : h->graphs)
+            if (g.key == key) {
+                HIPCHK(h, hipGraphLaunch(g.exec, s));
+                g.last_use = ++h->graph_clock;
+                ++h->graph_replays;
+                done = true;
+                break;
+            }
+        const bool seen_before = std::find(h->graph_seen.begin(), h->graph_seen.end(), key) != h->graph_seen.end();
+        if (!done && seen_before) {
+            // this key ran eagerly a moment ago: record it.  Capture runs on a private stream (the caller's may be the null
+            // stream, which cannot be captured) in thread-local mode; nothing executes until the launch below.
+            if (!h->capture_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->capture_stream, hipStreamNonBlocking));
+            hipGraph_t graph = nullptr;
+            hipGraphExec_t exec = nullptr;
+            if (hipStreamBeginCapture(h->capture_stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                const int erc = enqueue(h->capture_stream);
+                const hipError_t end = hipStreamEndCapture(h->capture_stream, &graph);
+                if (erc) {
+                    if (graph) (void)hipGraphDestroy(graph);
+                    return erc;
+                }
+                if (end == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                    (void)hipGraphDestroy(graph);
+                    if ((int)h->graphs.size() >= amx_handle_s::GRAPH_CAP) {
+                        // evict the least recently used recording once nothing on the stream can still be running it
+                        size_t lru = 0;
+                        for (size_t i = 1; i < h->graphs.size(); ++i)
+                            if (h->graphs[i].last_use < h->graphs[lru].last_use) lru = i;
+                        HIPCHK(h, hipStreamSynchronize(s));
+                        (void)hipGraphExecDestroy(h->graphs[lru].exec);
+                        h->graphs.erase(h->graphs.begin() + (long)lru);
+                    }
+                    HIPCHK(h, hipGraphLaunch(exec, s));
+                    amx_handle_s::GraphEntry entry;
+                    entry.key = key;
+                    entry.exec = exec;
+                    entry.last_use = ++h->graph_clock;
+                    h->graphs.push_back(std::move(entry));
+                    ++h->graph_captures;
+                    done = true;
+                } else {
+                    if (graph) (void)hipGraphDestroy(graph);
+                    (void)hipGetLastError();
+                    h->graph_broken = true;  // this runtime does not record the pass: stay eager from here on
+                }
+            } else {
+                (void)hipGetLastError();
+                h->graph_broken = true;
+            }
+        }
+        if (!done && !seen_before) {
+            if ((int)h->graph_seen.size() >= amx_handle_s::GRAPH_SEEN) h->graph_seen.erase(h->graph_seen.begin());
+            h->graph_seen.push_back(std::move(key));
+        }
+    }
+    if (!done && (rc = enqueue(s))) return rc;
+    // the pass's non-finite frame count travels to a pinned slot behind it; the next call reads it (see range_poll)
+    if (!(flags & AMX_FLAG_NO_RANGE_CHECK) && (rc = range_record(h, (flags & AMX_FLAG_CONTINUE) != 0, s))) return rc;
     if (flags & AMX_FLAG_HOST_IO) {
         HIPCHK(h, hipMemcpyAsync(out, d_out, (size_t)total * 4, hipMemcpyDeviceToHost, s));
         HIPCHK(h, hipStreamSynchronize(s));
@@ -1631,7 +1835,7 @@ extern "C" int amx_synchronize(amx_handle h, void* stream) {
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
     HIPCHK(h, hipGetLastError());
-    return AMX_OK;
+    return range_poll(h, true);  // every pass issued has completed: AMX_ERANGE if one of them left the range of the planes
 }
 
 extern "C" int amx_check_finite(amx_handle h, void* stream, int64_t* frames) {
@@ -1645,10 +1849,20 @@ extern "C" int amx_check_finite(amx_handle h, void* stream, int64_t* frames) {
     HIPCHK(h, hipMemsetAsync(h->nonfinite, 0, 4, s));  // a check closes its reporting period
     HIPCHK(h, hipStreamSynchronize(s));
     if (frames) *frames = count;
+    // an explicit check also consumes the pending reports of earlier passes (the stream has drained: their slots are complete)
+    const int earlier = range_poll(h, true);
+    if (count == 0 && earlier) return earlier;
     if (count > 0)
         return fail(h, AMX_ERANGE, std::to_string(count) + " valid frame(s) of the last forward pass hold non-finite logits: an activation left the "
                                    "range of the 16-bit planes (fp16: |x| <= 65504) or the input was not finite; the bf16 planes "
                                    "(precision bf16x3) have the range of fp32");
+    return AMX_OK;
+}
+
+extern "C" int amx_graph_info(amx_handle h, int64_t* captures, int64_t* replays) {
+    if (!h) return AMX_EINVAL;
+    if (captures) *captures = h->graph_captures;
+    if (replays) *replays = h->graph_replays;
     return AMX_OK;
 }
 

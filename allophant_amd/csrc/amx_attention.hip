@@ -729,7 +729,7 @@ void launch_attn2_layout(const AttnParams& p, int cus, hipStream_t stream) {
     // WAVES == 4: one item per workgroup -- the hardware dispatcher hands them out as workgroups retire, which balances the two
     // workgroups of a CU (the younger one loses the issue arbitration and runs ~20 % slower: with a static split of the items
     // it sets the span).  AMX_ATTN2_PERSISTENT=1: developer A/B switch
-    static const bool persistent4 = getenv("AMX_ATTN2_PERSISTENT") && atoi(getenv("AMX_ATTN2_PERSISTENT")) != 0;
+    static const bool persistent4 = dev_switch("AMX_ATTN2_PERSISTENT");
     if (WAVES == 4 && !persistent4) grid = items;
     hipLaunchKernelGGL((attn2_kernel<T, NT, PACKED, WAVES, STAGES>), dim3((unsigned)grid), dim3(WAVES * 64), lds, stream, p, items);
 }
@@ -775,11 +775,11 @@ void launch_attn_any(const AttnParams& p, hipStream_t stream) {
         cus = hipGetDeviceProperties(&prop, current_device()) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     const int64_t wg8 = (int64_t)p.N * p.H * ((p.T + 255) / 256);
-    static const int force = getenv("AMX_ATTN_WAVES") ? atoi(getenv("AMX_ATTN_WAVES")) : 0;  // developer A/B switch
+    static const int force = dev_int("AMX_ATTN_WAVES", 0);  // developer A/B switch
     {
         // 64 queries per wave (attn2_kernel, 256-query workgroups) for long key loops on a full chip (AMX_ATTN_V2 = 0 / 1 forces
         // the choice: developer A/B switch)
-        static const int v2 = getenv("AMX_ATTN_V2") ? atoi(getenv("AMX_ATTN_V2")) : -1;
+        static const int v2 = dev_int("AMX_ATTN_V2", -1);
         // (crossover measured at 12-15 key tiles per item with the chip full: T = 749 123 -> 147 us, T = 999 235 -> 221,
         // T = 1499 246 -> 234, T = 1999 640 -> 558, T = 2999 849 -> 752; one utterance alone keeps the 32-query waves)
         const bool fits = wg8 * 2 >= 3 * (int64_t)cus && p.T >= 960;
@@ -791,7 +791,7 @@ void launch_attn_any(const AttnParams& p, hipStream_t stream) {
     const bool small = force ? force == 4 : wg8 * 2 <= cus;
     // ... and when even the 128-query workgroups are at most one per CU, the key tiles of a query block are split over two wave
     // groups (KS = 2): two waves per SIMD instead of one, half the serial key loop (AMX_ATTN_KSPLIT=0: developer A/B switch)
-    static const bool no_ksplit = getenv("AMX_ATTN_KSPLIT") && atoi(getenv("AMX_ATTN_KSPLIT")) == 0;
+    static const bool no_ksplit = dev_int("AMX_ATTN_KSPLIT", 1) == 0;
     const int64_t wg4 = (int64_t)p.N * p.H * ((p.T + 127) / 128);
     // (tools/attn_bench.hip, per launch: 4 x 10 s 23.0 -> 21.2 us, 1 x 10 s 19.2 -> 17.4, 2 x 20 s 38.7 -> 34.4; 1 x 3 s -- three key
     // tiles -- 10.3 -> 10.9: from six tiles on)

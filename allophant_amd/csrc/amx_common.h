@@ -2,8 +2,23 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#ifdef AMX_DEVELOPER
+#include <cstdlib>
+#endif
 
 namespace amx {
+
+// Developer A/B switches.  The PRODUCT library reads no environment variable on the compute path (the one variable of the
+// library is AMX_RCCL_LIBRARY in amx_dist.hip, which names a file, not a behaviour): these helpers are constants there and
+// the switch names do not even reach the binary.  `make DEVELOPER=1` (-DAMX_DEVELOPER; tools/ab_build.sh, the A/B scripts under
+// tools/) builds the library in which they read the environment.
+#ifdef AMX_DEVELOPER
+inline bool dev_switch(const char* name) { const char* v = getenv(name); return v && atoi(v) != 0; }
+inline int dev_int(const char* name, int otherwise) { const char* v = getenv(name); return v ? atoi(v) : otherwise; }
+#else
+constexpr bool dev_switch(const char*) { return false; }
+constexpr int dev_int(const char*, int otherwise) { return otherwise; }
+#endif
 
 typedef _Float16 f16;
 typedef __bf16 bf16;
@@ -292,6 +307,8 @@ void launch_conv0(int prec, const float* audio, const int64_t* lengths, const fl
 // fp64 statistics into `partial` (conv0_groupnorm_partial_bytes) -> scale / shift [N, C] -> the conv0 kernel with the affine
 // form y = conv * scale + shift.  gamma / beta: the GroupNorm affine parameters [C]
 size_t conv0_groupnorm_partial_bytes(int N, int T1, int C);
+// dynamic LDS the conv-0 kernels request for this first-layer geometry (must stay <= 64 KiB: checked by amx_create)
+size_t conv0_window_lds_bytes(int k, int stride, int group_norm);
 void launch_conv0_groupnorm(int prec, const float* audio, const int64_t* lengths, const float* mean_rstd, int N, int64_t L, int T1,
                             int C, int k, int stride, const float* w, const float* b, const float* gamma, const float* beta,
                             float eps, int do_normalize, double* partial, float* scale, float* shift, void* out, int64_t out_plane,

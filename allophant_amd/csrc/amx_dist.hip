@@ -30,6 +30,7 @@ struct Rccl {
     result_t (*recv)(void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
     const char* (*error_string)(result_t) = nullptr;
     bool ok = false;
+    std::string why;  // why `ok` is false
 };
 
 Rccl& rccl() {
@@ -40,8 +41,15 @@ Rccl& rccl() {
         // holds it outside the global symbol scope (a Python process: torch bundles its own librccl and loads it locally)
         void* where = RTLD_DEFAULT;
         if (const char* path = getenv("AMX_RCCL_LIBRARY")) {
+            // an explicitly named library that does not load is an error, not a reason to bind whatever librccl the global
+            // scope happens to hold: a second copy would be handed a communicator it did not create
             void* h = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
-            if (h) where = h;
+            if (!h) {
+                const char* e = dlerror();
+                r.why = std::string("AMX_RCCL_LIBRARY=") + path + " could not be loaded: " + (e ? e : "unknown dlopen error");
+                return;
+            }
+            where = h;
         }
         r.group_start = (result_t (*)())dlsym(where, "ncclGroupStart");
         r.group_end = (result_t (*)())dlsym(where, "ncclGroupEnd");
@@ -49,6 +57,9 @@ Rccl& rccl() {
         r.recv = (result_t (*)(void*, size_t, int, int, comm_t, hipStream_t))dlsym(where, "ncclRecv");
         r.error_string = (const char* (*)(result_t))dlsym(where, "ncclGetErrorString");
         r.ok = r.group_start && r.group_end && r.send && r.recv;
+        if (!r.ok)
+            r.why = "no RCCL in this process: amx_gather_outputs uses the ncclSend / ncclRecv of the library the caller's communicator "
+                    "was created with (link or load librccl before the first call, or name it in AMX_RCCL_LIBRARY)";
     });
     return r;
 }
@@ -71,9 +82,7 @@ extern "C" int amx_gather_outputs(void* nccl_comm, int rank, int world, int root
     if ((count > 0 && !send) || (n_local > 0 && !send_lengths)) return fail(AMX_EINVAL, "null send buffer");
     if (rank == root && ((count > 0 && !recv) || (n_local > 0 && !recv_lengths))) return fail(AMX_EINVAL, "the root rank needs receive buffers");
     Rccl& r = rccl();
-    if (!r.ok)
-        return fail(AMX_ESTATE, "no RCCL in this process: amx_gather_outputs uses the ncclSend / ncclRecv of the library the caller's "
-                                "communicator was created with (link or load librccl before the first call)");
+    if (!r.ok) return fail(AMX_ESTATE, r.why);
     hipStream_t s = (hipStream_t)stream;
     auto check = [&](result_t rc, const char* what) {
         if (rc == 0) return AMX_OK;

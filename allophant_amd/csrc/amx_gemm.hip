@@ -35,7 +35,7 @@ int device_cus() {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
         // developer switch: size the persistent grids for a CU-masked stream (tools/two_stream_probe.py)
-        if (getenv("AMX_FORCE_CUS") && atoi(getenv("AMX_FORCE_CUS")) > 0) cus = atoi(getenv("AMX_FORCE_CUS"));
+        if (dev_int("AMX_FORCE_CUS", 0) > 0) cus = dev_int("AMX_FORCE_CUS", 0);
         if (cus <= 0) cus = 256;
         cus -= cus % 8;  // the tile order assumes sequence numbers i and i + grid share an XCD
         if (cus < 8) cus = 8;
@@ -65,7 +65,7 @@ bool ln_eligible(int NT, const GemmParams& p) {
 
 // the whole-line kernel (gemm_ln_il_kernel) takes the product: the one that understands the tap-minor K order
 bool ln_uses_il(int NT, const GemmParams& p) {
-    static const bool plain_loop = getenv("AMX_LN_SEGMENT_LOOP") && atoi(getenv("AMX_LN_SEGMENT_LOOP")) != 0;  // developer A/B
+    static const bool plain_loop = dev_switch("AMX_LN_SEGMENT_LOOP");  // developer A/B
     const bool layout_ok = NT == 1 || (p.a_plane == PLANE_IL && p.w_plane == PLANE_IL && p.out_plane == PLANE_IL);
     return !plain_loop && layout_ok && p.K % (128 / NT) == 0;
 }
@@ -230,7 +230,7 @@ bool launch_gemm_pp(const GemmParams& p, hipStream_t stream) {
 }
 
 bool dma_tile_eligible(int NT, const GemmParams& p) {
-    static const bool off = getenv("AMX_NO_DMA_TILE") && atoi(getenv("AMX_NO_DMA_TILE")) != 0;  // developer A/B switch
+    static const bool off = dev_switch("AMX_NO_DMA_TILE");  // developer A/B switch
     if (off || p.K % BK != 0) return false;
     if (p.lda % 8 || p.ldw % 8 || p.a_plane % 8 || p.w_plane % 8 || p.a_batch_stride % 8 || p.za % 8 || p.zw % 8) return false;
     if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return false;
@@ -286,7 +286,7 @@ void launch_gemm_dma_shape(int shape, const GemmParams& q, int zdim, hipStream_t
 // half of the CUs (N = 1024 products of a few thousand rows: 64 tiles on 256 CUs) while 128 x 64 tiles fill them.
 // AMX_DMA_MAX_ROWS (developer switch) overrides the row threshold of the second rule.
 int dma_preferred_shape(int NT, const GemmParams& p) {
-    static const int max_rows = getenv("AMX_DMA_MAX_ROWS") ? atoi(getenv("AMX_DMA_MAX_ROWS")) : 4096;
+    static const int max_rows = dev_int("AMX_DMA_MAX_ROWS", 4096);
     const int shape = dma_tile_shape(NT, p, 1);
     if (!shape) return 0;
     if (p.M < 768) return shape;
@@ -390,7 +390,7 @@ static GemmParams with_vec_flag(const GemmParams& in) {
 bool gemm_fuses_ln(int prec, const GemmParams& p_in) { return ln_eligible(prec_planes(prec), with_vec_flag(p_in)); }
 
 int gemm_ln_tap_minor_slice(int prec, const GemmParams& p_in) {
-    static const bool tap_major = getenv("AMX_LN_TAP_MAJOR") && atoi(getenv("AMX_LN_TAP_MAJOR")) != 0;  // developer A/B switch
+    static const bool tap_major = dev_switch("AMX_LN_TAP_MAJOR");  // developer A/B switch
     const int NT = prec_planes(prec);
     const GemmParams p = with_vec_flag(p_in);
     if (tap_major || !ln_eligible(NT, p) || !ln_uses_il(NT, p)) return 0;

@@ -482,11 +482,13 @@ __global__ void conv0_gn_final_kernel(const double* __restrict__ partial, int bl
 // One wave per row, D <= 1024, D % 4 == 0, row kept in registers (float4 x 4 per lane).
 // ----------------------------------------------------------------------------------------------------------------
 template <typename T, int NT>
-__global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ x, int64_t ldx, int64_t M, int D,
+// (x and out_f32 carry no __restrict__: the post-LN encoder normalises the residual stream IN PLACE, out_f32 == x; a wave loads
+// its whole row into registers before it stores any of it, and rows belong to one wave each)
+__global__ __launch_bounds__(256) void rownorm_kernel(const float* x, int64_t ldx, int64_t M, int D,
                                                       const float* __restrict__ g1, const float* __restrict__ b1, int gelu,
                                                       const float* __restrict__ g2, const float* __restrict__ b2,
                                                       float eps1, float eps2, T* __restrict__ out_p, int64_t out_plane,
-                                                      int64_t ldp, float* __restrict__ out_f32, int64_t ldo,
+                                                      int64_t ldp, float* out_f32, int64_t ldo,
                                                       const int* __restrict__ row_off, const int* __restrict__ frame_len, int T_rows) {
     const int lane = threadIdx.x & 63;
     int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1086,6 +1088,14 @@ void launch_conv0(int prec, const float* audio, const int64_t* lengths, const fl
     }
 }
 
+// dynamic LDS of the conv-0 kernels (the staged audio window of a workgroup): amx_create refuses strides whose window would
+// pass the 64 KiB every kernel may use without raising its limit -- a launch over it would fail and leave stale outputs
+size_t conv0_window_lds_bytes(int k, int stride, int group_norm) {
+    const size_t apply = (size_t)(C0_FRAMES * stride + k) * sizeof(float);
+    const size_t stats = group_norm ? (size_t)((GN_FRAMES - 1) * stride + k) * sizeof(float) : 0;
+    return apply > stats ? apply : stats;
+}
+
 size_t conv0_groupnorm_partial_bytes(int N, int T1, int C) {
     return (size_t)N * ((T1 + GN_FRAMES - 1) / GN_FRAMES) * C * 2 * sizeof(double);
 }
@@ -1096,7 +1106,7 @@ void launch_conv0_groupnorm(int prec, const float* audio, const int64_t* lengths
                             int skip_padding, hipStream_t s) {
     const int blocks = (T1 + GN_FRAMES - 1) / GN_FRAMES;
     const size_t lds = (size_t)((GN_FRAMES - 1) * stride + k) * sizeof(float);
-    static const bool plain_stats = getenv("AMX_GN_PLAIN_STATS") && atoi(getenv("AMX_GN_PLAIN_STATS")) != 0;  // developer A/B switch
+    static const bool plain_stats = dev_switch("AMX_GN_PLAIN_STATS");  // developer A/B switch
     if (k == 10 && C == 512 && !plain_stats) {
         // register-blocked form (wav2vec 2.0 shape); its LDS also holds the 4 x 512 x 2 fp64 partials of the block
         const size_t lds8 = lds > (size_t)4 * 512 * 2 * sizeof(double) ? lds : (size_t)4 * 512 * 2 * sizeof(double);

@@ -45,6 +45,8 @@ class Batch:
             self.lengths.to(device, non_blocking=non_blocking, copy=copy),
             self.language_ids.to(device, non_blocking=non_blocking, copy=copy),
         )
+        if getattr(self, "_padded", False):
+            moved._padded = True  # a slice of a larger batch (parallel.shard_batch(keep_length=True)): L may exceed max(lengths)
         slot = getattr(self, "_pinned_slot", None)
         if slot is not None:
             if moved.audio_features.device.type == "cuda" and non_blocking:
@@ -284,9 +286,15 @@ class Estimator:
         self._inventory = tfi_cpu
 
     def predict(self, batch: Batch, target_feature_indices: Optional[Tensor] = None, log_probabilities: bool = True,
-                _keep_hidden: bool = False, _timing: bool = False, _no_pack: bool = False) -> Predictions:
+                _keep_hidden: bool = False, _timing: bool = False, _no_pack: bool = False, _no_graph: bool = False,
+                _out: Optional[Tensor] = None) -> Predictions:
         """``Estimator.predict`` (reference estimator.py:1035-1046).  ``_no_pack`` (test hook) keeps the padded row layout
-        through the encoder layers of a ragged batch (``AMX_FLAG_NO_PACK``)."""
+        through the encoder layers of a ragged batch (``AMX_FLAG_NO_PACK``); ``_no_graph`` (test hook) enqueues the pass launch
+        by launch (``AMX_FLAG_NO_GRAPH``); ``_out`` (test / benchmark hook) is a flat fp32 device buffer to write the outputs into.
+
+        Safe by default: the reference computes in fp32; here an activation beyond the range of the fp16 planes turns into
+        non-finite logits.  Such a batch raises ``FloatingPointError`` from the first ``predict`` / ``synchronize`` issued after
+        the offending pass has finished on the GPU (no host synchronisation is added: see ``amx_forward``)."""
         if self._spec.get("embedding_size"):
             if target_feature_indices is None:
                 if self._training_inventory is None:
@@ -304,7 +312,8 @@ class Estimator:
         N, L = audio.shape
         if lengths.numel() != N:
             raise ValueError("lengths must have one entry per utterance")
-        if N > 0 and int(lengths.max()) != L:
+        padded = bool(getattr(batch, "_padded", False))  # a block of a larger batch that keeps the global padded length
+        if N > 0 and int(lengths.max()) != L and not (padded and int(lengths.max()) <= L):
             raise ValueError("the batch must be padded to exactly max(lengths) (reference utils.py:62-63, acoustic_model.py:765-767)")
         with torch.cuda.device(self._device):
             n_out = C.c_int()
@@ -315,7 +324,12 @@ class Estimator:
             descs = (_lib.AmxOutputDesc * n_out.value)()
             code = self._lib.amx_output_layout(self._handle, N, L, descs, C.byref(n_out), C.byref(T), C.byref(total))
             _lib.check(self._lib, self._handle, code)
-            flat = torch.empty(total.value, dtype=torch.float32, device=self._device)
+            if _out is not None:
+                if _out.dtype != torch.float32 or _out.device != self._device or _out.numel() < total.value or not _out.is_contiguous():
+                    raise ValueError("_out must be a contiguous fp32 buffer on the estimator's device with room for every output")
+                flat = _out.view(-1)[: total.value]
+            else:
+                flat = torch.empty(total.value, dtype=torch.float32, device=self._device)
             out_lengths = torch.empty(N, dtype=torch.int64)
             flags = 0 if log_probabilities else _lib.FLAG_RAW_LOGITS
             if _keep_hidden:
@@ -324,6 +338,10 @@ class Estimator:
                 flags |= _lib.FLAG_TIMING
             if _no_pack:
                 flags |= _lib.FLAG_NO_PACK
+            if padded:
+                flags |= _lib.FLAG_PADDED
+            if _no_graph:
+                flags |= _lib.FLAG_NO_GRAPH
             stream = torch.cuda.current_stream(self._device).cuda_stream
             n_max = int(self._lib.amx_max_utterances(self._handle, L))
             if N <= n_max:
@@ -438,6 +456,12 @@ class Estimator:
         _lib.check(self._lib, self._handle, self._lib.amx_timing_fetch(self._handle, ms, launches, n))
         return {k: (float(ms[i]), int(launches[i])) for i, k in enumerate(_lib.KERNEL_CLASSES)}
 
+    def graph_info(self) -> Tuple[int, int]:
+        """(forward passes recorded into HIP graphs, passes replayed from one) so far -- ``amx_graph_info``."""
+        captures, replays = C.c_int64(0), C.c_int64(0)
+        _lib.check(self._lib, self._handle, self._lib.amx_graph_info(self._handle, C.byref(captures), C.byref(replays)))
+        return int(captures.value), int(replays.value)
+
     def check_finite(self) -> None:
         """Range check of the last ``predict`` (``amx_check_finite``; no upstream counterpart -- the reference computes in
         fp32): waits for the stream and raises ``FloatingPointError`` when a valid frame holds non-finite logits, i.e. an
@@ -447,6 +471,8 @@ class Estimator:
         _lib.check(self._lib, self._handle, self._lib.amx_check_finite(self._handle, C.c_void_p(stream), None))
 
     def synchronize(self) -> None:
+        """Waits for the stream; raises ``FloatingPointError`` if a pass issued since the last report left the range of the
+        planes (``amx_synchronize`` -> ``AMX_ERANGE``)."""
         stream = torch.cuda.current_stream(self._device).cuda_stream
         _lib.check(self._lib, self._handle, self._lib.amx_synchronize(self._handle, C.c_void_p(stream)))
 

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 from typing import Optional
 
-AMX_ABI_VERSION = 4
+AMX_ABI_VERSION = 5
 AMX_MAX_CONV = 8
 AMX_MAX_DEPS = 64
 AMX_NAME_LEN = 48
@@ -17,6 +17,7 @@ AMX_NAME_LEN = 48
 AMX_OK, AMX_EINVAL, AMX_EHIP, AMX_ESTATE, AMX_ENOMEM, AMX_ERANGE = 0, -1, -2, -3, -4, -5
 PRECISIONS = {"bf16": 0, "f16": 1, "bf16x3": 2, "f16x3": 3}
 FLAG_HOST_IO, FLAG_RAW_LOGITS, FLAG_KEEP_HIDDEN, FLAG_TIMING, FLAG_PADDED, FLAG_NO_PACK, FLAG_CONTINUE = 1, 2, 4, 8, 16, 32, 64
+FLAG_NO_GRAPH, FLAG_NO_RANGE_CHECK = 128, 256
 NORM_LAYER, NORM_GROUP = 0, 1
 KERNEL_CLASSES = ["gemm_pp", "gemm_tile", "attention", "rownorm", "conv0", "other", "gemm_ln", "conv_tail"]
 DEP_OUTPUT = -1
@@ -30,6 +31,7 @@ EXPORTS = [
     "amx_create", "amx_destroy", "amx_last_error", "amx_set_inventory", "amx_output_layout", "amx_forward",
     "amx_synchronize", "amx_greedy_ctc", "amx_debug_fetch", "amx_device_bytes", "amx_timing_fetch",
     "amx_max_utterances", "amx_greedy_ctc_emissions", "amx_check_finite", "amx_gather_outputs", "amx_dist_last_error",
+    "amx_graph_info",
 ]
 
 
@@ -95,6 +97,8 @@ def load() -> C.CDLL:
     lib.amx_forward.restype = i32
     lib.amx_synchronize.argtypes = [vp, vp]
     lib.amx_synchronize.restype = i32
+    lib.amx_graph_info.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
+    lib.amx_graph_info.restype = i32
     lib.amx_check_finite.argtypes = [vp, vp, C.POINTER(i64)]
     lib.amx_check_finite.restype = i32
     lib.amx_greedy_ctc.argtypes = [vp, vp, C.POINTER(i64), i32, i64, vp, vp, vp, vp, vp]

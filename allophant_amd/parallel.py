@@ -1,8 +1,9 @@
 """Utterance-level data parallelism over the GPUs of one node (one process per GPU, ``torch.distributed``; backend
 ``"nccl"`` is RCCL over xGMI on ROCm, ``"gloo"`` on CPU for the tests).
 
-The prediction path is embarrassingly parallel over utterances: no operator mixes batch rows, so
-a batch is cut into contiguous blocks of utterances, every rank runs the full forward pass on its block with a full
+The prediction path is embarrassingly parallel over utterances: no operator mixes batch rows -- for
+the wav2vec 2.0 variants without the attention mask or with the group-norm extractor only as long as the blocks keep the
+padded length of the global batch (``padding_sensitive`` / ``shard_batch(keep_length=True)``) --, so a batch is cut into contiguous blocks of utterances, every rank runs the full forward pass on its block with a full
 weight replica, and the only exchange is one gather of per-frame log-probabilities (plus the frame lengths) to rank 0,
 where the reference's decode loop consumes ``Predictions.outputs`` (run.py:765-774).  The reference itself is
 single-device (no DDP / NCCL anywhere upstream) -- this module is new functionality with no upstream counterpart.
@@ -30,13 +31,29 @@ def shard_bounds(n: int, world: int) -> List[Tuple[int, int]]:
     return bounds
 
 
-def shard_batch(batch: Batch, rank: int, world: int) -> Optional[Batch]:
+def padding_sensitive(spec) -> bool:
+    """True for the encoder variants whose results on VALID frames depend on the padded length of the batch tensor: the
+    group-norm feature extractor takes its GroupNorm statistics over every frame of the padded tensor, and a model called
+    without the attention mask (``use_attention_mask=False``) attends to every padded frame.  For the released Allophant
+    checkpoints (XLS-R: layer norm + attention mask) padding never reaches a valid frame and this is False."""
+    return spec.get("feat_extract_norm", "layer") == "group" or not spec.get("use_attention_mask", True)
+
+
+def shard_batch(batch: Batch, rank: int, world: int, keep_length: bool = False) -> Optional[Batch]:
     """Block ``rank`` of ``batch``, re-padded to its own longest utterance (the reference requires
-    ``L == max(lengths)``, utils.py:62-63).  Returns ``None`` for an empty block."""
+    ``L == max(lengths)``, utils.py:62-63).  Returns ``None`` for an empty block.
+
+    ``keep_length=True`` keeps the padded length of the GLOBAL batch instead (the block is marked as a slice of a larger
+    batch and ``Estimator.predict`` runs it with ``AMX_FLAG_PADDED``): required for ``padding_sensitive`` specs, whose
+    single-device result depends on that length -- with re-padded blocks the data-parallel output would differ from it."""
     lo, hi = shard_bounds(len(batch), world)[rank]
     if hi <= lo:
         return None
     lengths = batch.lengths[lo:hi]
+    if keep_length:
+        local = Batch(batch.audio_features[lo:hi].contiguous(), lengths, batch.language_ids[lo:hi])
+        local._padded = True
+        return local
     local_max = int(lengths.max())
     return Batch(batch.audio_features[lo:hi, :local_max].contiguous(), lengths, batch.language_ids[lo:hi])
 
@@ -104,16 +121,17 @@ def gather_predictions(local: Optional[Predictions], names_and_classes: List[Tup
 
 def data_parallel_predict(predict: Callable[[Batch], Predictions], batch: Batch, outputs: List[Tuple[str, int]],
                           device: torch.device, dst: int = 0, group=None,
-                          aliases: Optional[Dict[str, str]] = None) -> Optional[Predictions]:
+                          aliases: Optional[Dict[str, str]] = None, keep_length: bool = False) -> Optional[Predictions]:
     """One data-parallel ``predict`` over the ranks of ``group``: every rank takes its contiguous block of utterances
     (``shard_batch``), runs ``predict`` on it (e.g. ``lambda b: estimator.predict(b.to(device), tfi)``) and the
     log-probabilities are gathered to ``dst`` (``gather_predictions``), which gets the ``Predictions`` of the whole batch;
     the other ranks get ``None``.  ``outputs`` lists the distinct outputs as (name, classes) in output order and
     ``aliases`` the names that share storage with one of them (see ``unique_outputs``): a rank whose block is empty has no
-    local prediction to read them from."""
+    local prediction to read them from.  ``keep_length``: pass ``padding_sensitive(spec)`` -- the blocks then keep the padded
+    length of the global batch (see ``shard_batch``)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    local_batch = shard_batch(batch, rank, world)
+    local_batch = shard_batch(batch, rank, world, keep_length=keep_length)
     local = predict(local_batch) if local_batch is not None else None
     return gather_predictions(local, outputs, len(batch), device, dst=dst, group=group, aliases=aliases)
 

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define AMX_ABI_VERSION 4
+#define AMX_ABI_VERSION 5
 
 #define AMX_MAX_CONV 8
 #define AMX_MAX_DEPS 64
@@ -34,7 +34,9 @@ extern "C" {
 #define AMX_EHIP (-2)     /* HIP runtime failure */
 #define AMX_ESTATE (-3)   /* call order violated (e.g. composition model without an inventory) */
 #define AMX_ENOMEM (-4)
-#define AMX_ERANGE (-5)   /* amx_check_finite: an activation left the range of the 16-bit planes (non-finite logits) */
+#define AMX_ERANGE (-5)   /* an activation left the range of the 16-bit planes (non-finite logits on valid frames): returned by
+                           * the first amx_forward / amx_synchronize after the offending pass has completed (ABI 5: safe by
+                           * default), and by amx_check_finite */
 
 /* arithmetic modes of the GEMM-shaped products (activations between kernels are 16-bit planes, residual stream,
  * LayerNorm, softmax and all accumulation are fp32):
@@ -59,6 +61,8 @@ extern "C" {
                                     reference itself requires L == max(lengths), utils.py:62-63) */
 #define AMX_FLAG_CONTINUE 64u    /* the call continues the range-check count of the previous call instead of restarting it: slices
                                   * 2.. of one over-long batch (amx_check_finite then reports on the whole batch) */
+#define AMX_FLAG_NO_GRAPH 128u   /* enqueue the pass launch by launch even when a HIP graph of it exists or could be recorded */
+#define AMX_FLAG_NO_RANGE_CHECK 256u /* do not report non-finite logits of this pass through a later call (amx_check_finite still does) */
 #define AMX_FLAG_NO_PACK 32u     /* keep the padded [N, T] row layout through the encoder layers even for a ragged batch (the
                                   * default runs them on the valid frames only; results on valid frames are identical) */
 
@@ -179,10 +183,22 @@ int64_t amx_max_utterances(amx_handle h, int64_t L);
  *   out          fp32 `total` floats laid out per amx_output_layout; device pointer unless AMX_FLAG_HOST_IO
  *   out_lengths  int64 [N] frames per utterance (`Predictions.lengths`), HOST pointer
  *   stream       hipStream_t (NULL = default stream).  Work is enqueued asynchronously; call amx_synchronize or
- *                synchronize the stream before reading `out` (with AMX_FLAG_HOST_IO the call returns synchronised). */
+ *                synchronize the stream before reading `out` (with AMX_FLAG_HOST_IO the call returns synchronised).
+ *
+ * Launch collapse (ABI 5): a pass whose buffers, geometry, lengths, flags and inventory equal those of one of the last few passes is
+ * recorded into a HIP graph and replayed from then on -- one hipGraphLaunch instead of ~185 kernel launches (the host side of a
+ * step drops from ~12 to ~2 us per kernel); results are bitwise those of the eager pass.  AMX_FLAG_NO_GRAPH opts out;
+ * AMX_FLAG_TIMING / AMX_FLAG_KEEP_HIDDEN passes are never recorded.
+ *
+ * Range report (ABI 5, safe by default): the reference computes in fp32 and cannot overflow; the fp16 planes can (|x| <=
+ * 65504).  A pass that produced non-finite logits on valid frames makes the FIRST amx_forward / amx_synchronize issued after
+ * it has completed return AMX_ERANGE (that amx_forward enqueues nothing; call it again after handling the report).  No host
+ * synchronisation is added to the hot path: a call only reads the pinned counters of passes that have already finished. */
 int amx_forward(amx_handle h, const float* audio, const int64_t* lengths, int N, int64_t L, float* out,
                 int64_t* out_lengths, uint32_t flags, void* stream);
 int amx_synchronize(amx_handle h, void* stream);
+/* number of forward passes recorded into HIP graphs / replayed from one so far (measurement and test hook) */
+int amx_graph_info(amx_handle h, int64_t* captures, int64_t* replays);
 
 /* Range check of the last amx_forward on `stream` (no upstream counterpart: the reference computes in fp32).  The 16-bit
  * planes of the fp16 modes hold |x| <= 65504; weights are packed under a per-tensor power-of-two scale, so only an
@@ -234,7 +250,11 @@ int64_t amx_device_bytes(amx_handle h);
  * `recv` / `recv_lengths` may be NULL on the other ranks.  `nccl_comm` is an ncclComm_t the caller created (ncclCommInitRank, one
  * communicator per process); the work is enqueued on `stream` behind the forward pass, RCCL moves it over xGMI.  The library does
  * not link RCCL: it uses the ncclSend / ncclRecv of the RCCL already loaded in the process -- the one the communicator came from
- * (AMX_ESTATE if there is none).  Errors: amx_dist_last_error(). */
+ * (AMX_ESTATE if there is none, or if the library AMX_RCCL_LIBRARY names does not load).  A non-zero return on ANY rank must
+ * abort the job: the arguments only one rank can check (the root's receive buffers) fail there alone, and the sends the other
+ * ranks have already enqueued then never match.  Padding-sensitive models (feat_extract_norm = group or use_attention_mask = 0):
+ * every rank must run amx_forward with the padded length L of the GLOBAL batch and AMX_FLAG_PADDED, else the shards are not
+ * the function the single-device call computes.  Errors: amx_dist_last_error(). */
 int amx_gather_outputs(void* nccl_comm, int rank, int world, int root, const float* send, int64_t count, float* recv,
                        const int64_t* send_lengths, int n_local, int64_t* recv_lengths, void* stream);
 const char* amx_dist_last_error(void);

@@ -144,12 +144,17 @@ def feature_encoder(x: Tensor, state: Dict[str, Tensor], spec: Dict[str, Any]) -
 
 
 def wav2vec2_hidden_states(
-    audio: Tensor, lengths: Tensor, state: Dict[str, Tensor], spec: Dict[str, Any], keep_intermediates: bool = False
+    audio: Tensor, lengths: Tensor, state: Dict[str, Tensor], spec: Dict[str, Any], keep_intermediates: bool = False,
+    padded: bool = False,
 ) -> Tuple[List[Tensor], Tensor, Dict[str, Tensor]]:
-    """Returns (hidden_states list of [N,T,D] incl. final LN state, frame lengths, intermediates)."""
+    """Returns (hidden_states list of [N,T,D] incl. final LN state, frame lengths, intermediates).
+
+    ``padded`` (no upstream counterpart; the product's AMX_FLAG_PADDED): the batch is a block of a larger batch and keeps
+    that batch's padded length, ``audio.shape[1] >= max(lengths)`` -- the mask is built for that length, which is what the
+    reference computes for these utterances inside the larger batch."""
     eps = spec["eps"]
     inter: Dict[str, Tensor] = {}
-    mask = mask_sequence(lengths)
+    mask = mask_sequence(lengths, audio.shape[1] if padded else None)
     if mask.shape[1] != audio.shape[1]:
         raise ValueError("the batch must be padded to exactly max(lengths) (utils.py:62-63 / acoustic_model.py:765-767)")
     x = zero_mean_unit_var_norm(audio, lengths, mask) if spec.get("do_normalize", True) else audio
@@ -331,10 +336,11 @@ def projection_forward(
 def predict(
     audio: Tensor, lengths: Tensor, state: Dict[str, Tensor], spec: Dict[str, Any], tfi: Optional[Tensor] = None,
     category_offsets: Optional[Tensor] = None, log_probabilities: bool = True, keep_intermediates: bool = False,
+    padded: bool = False,
 ):
     """Estimator.predict restated.  Returns (outputs: name -> [T,N,C], frame lengths[, intermediates])."""
     with torch.inference_mode():
-        hidden, frame_lengths, inter = wav2vec2_hidden_states(audio, lengths, state, spec, keep_intermediates)
+        hidden, frame_lengths, inter = wav2vec2_hidden_states(audio, lengths, state, spec, keep_intermediates, padded)
         time_major = [h.transpose(0, 1) for h in hidden]
         logits = projection_forward(time_major, state, spec, tfi, category_offsets, frame_lengths)
         if log_probabilities:

@@ -418,3 +418,65 @@ def _overflow_worker(rank, world, port):
 
 def test_decoded_gather_refuses_alignments_beyond_the_capacity():
     mp.spawn(_overflow_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
+# ---- variants whose valid frames depend on the padded length (group norm over time / no attention mask) ----
+def _variant_setup():
+    encoder = S.tiny_encoder(1)
+    encoder.update(feat_extract_norm="group", conv_bias=False, stable_layer_norm=False, use_attention_mask=False)
+    spec = S.multitask_spec(encoder, ["syllabic"], embedding_size=16, train_phonemes=9, n_features=5)
+    state = synthetic.make_state_dict(spec, seed=7)
+    audio, lengths = synthetic.make_audio(4, 3000, seed=13, ragged=True)
+    tfi = synthetic.make_inventory(spec, 6, seed=7)
+    return spec, state, audio, lengths, tfi
+
+
+def _variant_predict(spec, state, batch, tfi):
+    from oracle import allophant_oracle as O
+
+    out, flen = O.predict(batch.audio_features, batch.lengths, state, spec, tfi, synthetic.category_offsets(spec),
+                          padded=bool(getattr(batch, "_padded", False)))
+    return Predictions(out, flen)
+
+
+def _variant_worker(rank, world, port, result_path):
+    from allophant_amd.parallel import padding_sensitive
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    spec, state, audio, lengths, tfi = _variant_setup()
+    assert padding_sensitive(spec)
+    full = Batch(audio, lengths, torch.zeros(len(lengths), dtype=torch.long))
+    names = [("syllabic", 4), ("phoneme", 7)]
+    kept = data_parallel_predict(lambda b: _variant_predict(spec, state, b, tfi), full, names, torch.device("cpu"), dst=0,
+                                 keep_length=padding_sensitive(spec))
+    repadded = data_parallel_predict(lambda b: _variant_predict(spec, state, b, tfi), full, names, torch.device("cpu"), dst=0)
+    if rank == 0:
+        torch.save({"kept": kept.outputs, "repadded": repadded.outputs, "lengths": kept.lengths}, result_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_padding_sensitive_variants_shard_with_the_global_length(tmp_path):
+    """Group-norm / unmasked wav2vec 2.0: the single-device result depends on the padded length of the batch tensor, so the
+    shards keep it (``shard_batch(keep_length=True)`` -> AMX_FLAG_PADDED); with re-padded shards the valid frames differ."""
+    from allophant_amd.parallel import padding_sensitive
+
+    assert not padding_sensitive(_setup()[0])  # XLS-R form: layer norm + attention mask
+    world = 2
+    result_path = str(tmp_path / "variant.pt")
+    mp.spawn(_variant_worker, args=(world, _free_port(), result_path), nprocs=world, join=True)
+    got = torch.load(result_path)
+    spec, state, audio, lengths, tfi = _variant_setup()
+    single = _variant_predict(spec, state, Batch(audio, lengths, torch.zeros(len(lengths), dtype=torch.long)), tfi)
+    assert torch.equal(got["lengths"], single.lengths)
+    worst_repadded = 0.0
+    for name, expected in single.outputs.items():
+        valid = (torch.arange(expected.shape[0]).unsqueeze(1) < single.lengths.unsqueeze(0)).unsqueeze(-1)
+        assert got["kept"][name].shape == expected.shape
+        assert ((got["kept"][name] - expected).abs() * valid).max().item() < 1e-4, name
+        g = got["repadded"][name]
+        worst_repadded = max(worst_repadded, ((g - expected[: g.shape[0]]).abs() * valid[: g.shape[0]]).max().item())
+    assert worst_repadded > 1e-2  # what the advisor measured: re-padded shards are a different function for these specs

@@ -1,0 +1,146 @@
+"""Launch collapse (ABI 5): a forward pass recorded into a HIP graph and replayed must be BITWISE the eager pass.
+
+``amx_forward`` records a pass when the same key (buffers, geometry, lengths, flags, inventory, workspace generation) occurs
+twice in a row and replays it while it recurs.  Checked here at XLS-R-300m shape on the geometries the review named -- 1 x 3 s,
+4 x 10 s (BASELINE config 3's per-GPU share), 32 x 10 s (config 2, the batch ``bench.py`` times) -- padded (equal lengths) and
+packed rows (ragged), plus what could go wrong with a cache of recordings: a second inventory, other lengths at the same
+geometry, another output buffer, and a workspace that grows after graphs exist.
+
+The reference has nothing to mirror here (its per-head Python loop, acoustic_model.py:492-522, is what the collapse replaces).
+"""
+import pytest
+import torch
+
+from allophant_amd import spec as S, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def amd():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from allophant_amd import estimator, lib
+
+    assert lib.load() is not None
+    return estimator
+
+
+@pytest.fixture(scope="module")
+def model(amd):
+    spec = S.multitask_spec(S.xlsr_300m_encoder(), allophone_layer=True)
+    spec["shared_phones"] = 80
+    state = synthetic.make_state_dict(spec, seed=0)
+    est = amd.Estimator(spec, state, "cuda:0", "f16x3")
+    yield spec, est
+    est.close()
+
+
+def _total(pred):
+    return pred._flat.numel()
+
+
+def _eager_then_graph(amd, est, batch, tfi, repeats=5, out=None):
+    """Eager reference pass, then `repeats` ordinary passes into one poisoned buffer: every one must equal the eager bits;
+    returns (graphs recorded, passes replayed) during the ordinary passes."""
+    eager = est.predict(batch, tfi, True, _no_graph=True)
+    torch.cuda.synchronize()
+    want = eager._flat.clone()
+    buf = out if out is not None else torch.empty(_total(eager), dtype=torch.float32, device="cuda")
+    c0, r0 = est.graph_info()
+    for i in range(repeats):
+        buf.fill_(float("nan"))
+        pred = est.predict(batch, tfi, True, _out=buf)
+        torch.cuda.synchronize()
+        assert torch.equal(pred.lengths.cpu(), eager.lengths.cpu())
+        assert torch.equal(pred._flat, want), f"pass {i} differs from the eager pass"
+    c1, r1 = est.graph_info()
+    return c1 - c0, r1 - r0
+
+
+@pytest.mark.parametrize("n,seconds", [(1, 3), (4, 10), (32, 10)])
+def test_graph_replay_is_bitwise_the_eager_pass_padded(amd, model, n, seconds):
+    spec, est = model
+    tfi = synthetic.make_inventory(spec, 27, seed=0)
+    audio, lengths = synthetic.make_audio(n, seconds * 16000, seed=1234)
+    batch = amd.Batch(audio.cuda(), lengths, torch.zeros(n, dtype=torch.long))
+    captured, replayed = _eager_then_graph(amd, est, batch, tfi)
+    # pass 0 re-zeroes Q / K / V for the new geometry (its own key), pass 1 is the first of the steady key, pass 2 records
+    assert captured == 1 and replayed >= 2, (captured, replayed)
+
+
+@pytest.mark.parametrize("n,seconds", [(4, 10), (32, 10)])
+def test_graph_replay_is_bitwise_the_eager_pass_packed_rows(amd, model, n, seconds):
+    spec, est = model
+    tfi = synthetic.make_inventory(spec, 27, seed=0)
+    audio, lengths = synthetic.make_audio(n, seconds * 16000, seed=99, ragged=True)
+    assert int(lengths.min()) < int(lengths.max())
+    batch = amd.Batch(audio.cuda(), lengths, torch.zeros(n, dtype=torch.long))
+    captured, replayed = _eager_then_graph(amd, est, batch, tfi)
+    assert captured >= 1 and replayed >= 1, (captured, replayed)
+    # other lengths at the SAME (N, L): a recording of the first batch must not be replayed for them
+    other = lengths.clone()
+    other[1:] = torch.clamp(other[1:] - 4000, min=8000)
+    other[0] = lengths.max()
+    audio2 = audio.clone()
+    for i in range(n):
+        audio2[i, int(other[i]):] = 0
+    batch2 = amd.Batch(audio2.cuda(), other, torch.zeros(n, dtype=torch.long))
+    _eager_then_graph(amd, est, batch2, tfi)
+    # ... and the first batch again still gives its own bits (its recording, or a fresh pass)
+    _eager_then_graph(amd, est, batch, tfi, repeats=2)
+
+
+def test_recordings_follow_the_inventory_and_the_buffers(amd, model):
+    spec, est = model
+    audio, lengths = synthetic.make_audio(4, 160000, seed=7)
+    batch = amd.Batch(audio.cuda(), lengths, torch.zeros(4, dtype=torch.long))
+    small, large = synthetic.make_inventory(spec, 27, seed=0), synthetic.make_inventory(spec, 200, seed=3)
+    _eager_then_graph(amd, est, batch, small)
+    _eager_then_graph(amd, est, batch, large)   # other output widths, other composed matrix: its own recording
+    _eager_then_graph(amd, est, batch, small, repeats=3)
+    # alternating inventories in one loop, fresh output buffers from the caching allocator (the façade's default)
+    want = {}
+    for name, tfi in (("small", small), ("large", large)):
+        p = est.predict(batch, tfi, True, _no_graph=True)
+        torch.cuda.synchronize()
+        want[name] = p._flat.clone()
+    for _ in range(4):
+        for name, tfi in (("small", small), ("large", large)):
+            p = est.predict(batch, tfi, True)
+            torch.cuda.synchronize()
+            assert torch.equal(p._flat, want[name]), name
+
+
+def test_a_growing_workspace_drops_the_recordings(amd, model):
+    spec, est = model
+    tfi = synthetic.make_inventory(spec, 27, seed=0)
+    audio, lengths = synthetic.make_audio(2, 48000, seed=5)
+    batch = amd.Batch(audio.cuda(), lengths, torch.zeros(2, dtype=torch.long))
+    _eager_then_graph(amd, est, batch, tfi)
+    # a much larger batch than anything this module ran: workspace buffers are reallocated, recorded pointers are stale
+    big_audio, big_lengths = synthetic.make_audio(40, 176000, seed=6)
+    big = amd.Batch(big_audio.cuda(), big_lengths, torch.zeros(40, dtype=torch.long))
+    _eager_then_graph(amd, est, big, tfi, repeats=3)
+    captured, replayed = _eager_then_graph(amd, est, batch, tfi)
+    assert captured == 1 and replayed >= 2, (captured, replayed)  # recorded afresh against the new buffers
+
+
+def test_raw_logits_and_host_io_passes_through_graphs(amd, model):
+    """Flags are part of the key: `log_probabilities=False` after a recorded log-prob pass gives raw logits, not a replay."""
+    spec, est = model
+    tfi = synthetic.make_inventory(spec, 27, seed=0)
+    audio, lengths = synthetic.make_audio(2, 48000, seed=15)
+    batch = amd.Batch(audio.cuda(), lengths, torch.zeros(2, dtype=torch.long))
+    _eager_then_graph(amd, est, batch, tfi)
+    raw_eager = est.predict(batch, tfi, False, _no_graph=True)
+    torch.cuda.synchronize()
+    want = raw_eager._flat.clone()
+    for _ in range(4):
+        raw = est.predict(batch, tfi, False)
+        torch.cuda.synchronize()
+        assert torch.equal(raw._flat, want)
+    logp = est.predict(batch, tfi, True)
+    torch.cuda.synchronize()
+    assert not torch.equal(logp._flat, want)
+    assert torch.allclose(torch.log_softmax(raw.outputs["phoneme"], -1), logp.outputs["phoneme"], atol=1e-5)

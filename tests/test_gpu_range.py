@@ -12,7 +12,8 @@ north-star gate) on checkpoints with
   * LayerNorm gains up to 8,
   * one residual-stream channel pinned near 1e3 (the "outlier channel" of trained wav2vec 2.0 / XLS-R models),
 
-and a checkpoint whose activations really leave the fp16 range is refused loudly (``Estimator.check_finite`` ->
+and a checkpoint whose activations really leave the fp16 range is refused loudly without being asked (the next ``predict`` /
+``synchronize`` raises; ``Estimator.check_finite`` still exists ->
 ``FloatingPointError``) while ``bf16x3`` (fp32 range) runs it.  Weights cannot leave the range: they are packed under
 per-tensor power-of-two scales (``amx_create``).
 """
@@ -151,10 +152,33 @@ def test_activation_overflow_is_refused_not_silent(amd):
     batch = amd.Batch(audio.cuda(), lengths, torch.zeros(2, dtype=torch.long))
     ref, ref_len = O.predict(audio, lengths, state, spec, tfi, synthetic.category_offsets(spec))
     assert all(torch.isfinite(v).all() for v in ref.values())
+    # safe by default (ABI 5): nobody calls check_finite() -- the overflow of pass k surfaces from the first predict() or
+    # synchronize() issued after pass k has finished on the GPU, without a host synchronisation on the hot path
     est = amd.Estimator(spec, state, "cuda:0", "f16x3")
     est.predict(batch, tfi)
     with pytest.raises(FloatingPointError, match="bf16x3"):
-        est.check_finite()
+        est.synchronize()
+    est.synchronize()  # the report was consumed by the call that raised it
+    est.predict(batch, tfi)
+    torch.cuda.synchronize()  # pass k has completed ...
+    with pytest.raises(FloatingPointError, match="EARLIER forward pass"):
+        est.predict(batch, tfi)  # ... so the next predict refuses to go on (and has enqueued nothing)
+    est.predict(batch, tfi)
+    with pytest.raises(FloatingPointError, match="bf16x3"):
+        est.check_finite()  # the explicit check still reports on the last pass
+    est.synchronize()  # ... and consumed the pending reports with it
+    # the same loop as a host that runs ahead of the GPU: the report arrives within a few calls, never silently dropped
+    raised = 0
+    for _ in range(12):
+        try:
+            est.predict(batch, tfi)
+        except FloatingPointError:
+            raised += 1
+    try:
+        est.synchronize()
+    except FloatingPointError:
+        raised += 1
+    assert raised >= 1
     est.close()
     wide = amd.Estimator(spec, state, "cuda:0", "bf16x3")
     pred = wide.predict(batch, tfi)

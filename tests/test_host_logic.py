@@ -128,6 +128,30 @@ def test_checkpoint_schema_round_trip(tmp_path):
     assert checkpoint.spec_from_checkpoint(plain)["hidden"] == 1024
 
 
+def test_encoder_table_is_cross_checked_against_the_weights():
+    """`MODEL_ID_ENCODERS` is written from memory: an entry that disagrees with the checkpoint's own tensors (conv biases,
+    conv norms, layer count, widths) is refused instead of silently dropping weights."""
+    encoder = S.tiny_encoder(1)
+    spec = S.baseline_spec(encoder, 7)
+    sd = synthetic.make_state_dict(spec, seed=1)
+    good = checkpoint.make_checkpoint(spec, sd, synthetic_encoder=True)
+    assert checkpoint.spec_from_checkpoint(good).get("conv_bias", True)
+    for wrong, needle in (({"conv_bias": False}, "conv_bias"), ({"feat_extract_norm": "group"}, "feat_extract_norm"),
+                          ({"layers": 3}, "encoder layers"), ({"ffn": 512}, "hidden / ffn")):
+        bad = checkpoint.make_checkpoint(spec, sd, synthetic_encoder=True)
+        bad["additional"]["amx_encoder"] = dict(bad["additional"]["amx_encoder"], **wrong)
+        with pytest.raises(ValueError, match=needle):
+            checkpoint.spec_from_checkpoint(bad)
+    # the group-norm variant's own state dict passes under its own description and fails under the XLS-R one
+    variant = dict(encoder, feat_extract_norm="group", conv_bias=False, stable_layer_norm=False, use_attention_mask=False)
+    vspec = S.baseline_spec(variant, 7)
+    vsd = synthetic.make_state_dict(vspec, seed=1)
+    checkpoint.spec_from_checkpoint(checkpoint.make_checkpoint(vspec, vsd, synthetic_encoder=True))
+    mixed = checkpoint.make_checkpoint(spec, vsd, synthetic_encoder=True)
+    with pytest.raises(ValueError, match="does not match the checkpoint's weights"):
+        checkpoint.spec_from_checkpoint(mixed)
+
+
 def test_time_layer_classifiers_round_trip_and_struct_fields():
     """`time_layer` (MultiheadAttentionConfig, config.py:596-610) survives checkpoint write/read, reaches the C ABI
     structs, and num_heads must divide the classifier width like nn.MultiheadAttention asserts."""

@@ -8,6 +8,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 TMP=$(mktemp -d)
 git -C "$ROOT" archive "$REV" allophant_amd/csrc include | tar -x -C "$TMP"
 mkdir -p "$ROOT/build/ab"
-make -C "$TMP/allophant_amd/csrc" -j4 OBJDIR="$TMP/obj" OUT="$ROOT/build/ab/$NAME.so" > /dev/null
+# DEVELOPER=1: the AMX_* A/B switches read the environment only in this build (the product library has none)
+make -C "$TMP/allophant_amd/csrc" -j4 DEVELOPER=1 OBJDIR="$TMP/obj" OUT="$ROOT/build/ab/$NAME.so" > /dev/null
 rm -rf "$TMP"
 ls -la "$ROOT/build/ab/$NAME.so"
