@@ -169,21 +169,21 @@ void launch_fixup(const GemmParams& p, int splits, hipStream_t stream) {
                        (int64_t)p.M * p.N);
 }
 
-template <typename T, int NT, int MI>
+template <typename T, int NT, int MI, int NI = 4>
 void launch_pp_tiles(const GemmParams& p, int splits, hipStream_t stream) {
     static OncePerDevice attr;
-    constexpr int lds = pp::lds_bytes(NT, MI);
+    constexpr int lds = pp::lds_bytes(NT, MI, NI);
     if (attr.first())
-        (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<T, NT, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    const int tiles = ((p.N + pp::BN - 1) / pp::BN) * ((p.M + MI * 32 - 1) / (MI * 32));
+        (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<T, NT, MI, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const int tiles = ((p.N + NI * 64 - 1) / (NI * 64)) * ((p.M + MI * 32 - 1) / (MI * 32));
     const int cus = device_cus();
     const int units = tiles * splits;
-    dim3 grid(units < cus ? units : cus, 1, 1);  // persistent: one 128-160-KiB-LDS workgroup per CU
+    dim3 grid(units < cus ? units : cus, 1, 1);  // persistent: one 112-160-KiB-LDS workgroup per CU
     if (splits > 1) {
-        hipLaunchKernelGGL((gemm_pp_kernel<T, NT, MI>), grid, dim3(512), lds, stream, split_view(p, splits));
+        hipLaunchKernelGGL((gemm_pp_kernel<T, NT, MI, NI>), grid, dim3(512), lds, stream, split_view(p, splits));
         if (!p.defer_fixup) launch_fixup<T, NT>(p, splits, stream);
     } else {
-        hipLaunchKernelGGL((gemm_pp_kernel<T, NT, MI>), grid, dim3(512), lds, stream, p);
+        hipLaunchKernelGGL((gemm_pp_kernel<T, NT, MI, NI>), grid, dim3(512), lds, stream, p);
     }
 }
 
@@ -191,41 +191,56 @@ void launch_pp_tiles(const GemmParams& p, int splits, hipStream_t stream) {
 // segment pair per K element (~ 0.0166 us; fitted to tools/gemm_bench `small` on MI355X):
 //   rounds of the persistent grid x (main loop of a work unit + its prologue / epilogue) + fix-up launch and slab traffic.
 // Config-2-sized products (>= one full round of 256-row tiles) always come out as (256 rows, 1 chunk).
-void pp_plan(int NT, const GemmParams& p, int* mi_out, int* splits_out) {
+// NI (W fragments per wave: 4 = 256-column tiles, 3 = 192-column tiles, see gemm_pp_kernel) is part of the plan: the narrower
+// tile costs 3/4 of the matrix work of a unit but moves 7/8 (256 rows) or 5/6 (128 rows) of its operand bytes and takes the
+// generic epilogue, priced as + 6 % on the loop and + 10 % on the per-unit overhead.
+void pp_plan(int NT, const GemmParams& p, int* mi_out, int* splits_out, int* ni_out) {
     const int cus = device_cus();
-    const double loop = (double)p.K * (NT > 1 ? 3 : 1);  // main loop of a 256-row tile
+    const double loop = (double)p.K * (NT > 1 ? 3 : 1);  // main loop of a 256 x 256 tile
+    static const bool no_narrow = dev_switch("AMX_NO_NARROW_TILES");  // developer A/B switch: 256-column tiles only
+    static const int force_ni = dev_int("AMX_PP_FORCE_NI", 0), force_mi = dev_int("AMX_PP_FORCE_MI", 0);  // developer: one tile shape
     double best = 1e30;
     *mi_out = 8;
     *splits_out = 1;
-    for (int mi = 8; mi >= 4; mi -= 4) {
-        const int tiles = ((p.N + pp::BN - 1) / pp::BN) * ((p.M + mi * 32 - 1) / (mi * 32));
-        const double per_unit = 480.0 + 60.0 * mi;  // prologue + epilogue of a work unit
-        int64_t smax = 1;
-        if (p.splitk_ws && p.K % 128 == 0) {
-            smax = std::min<int64_t>(p.K / 256, p.splitk_ws_elems / ((int64_t)p.M * p.N));
-            smax = std::min<int64_t>(smax, 32);
-        }
-        for (int sp = 1; sp <= smax; ++sp) {
-            if ((p.K / 128) % sp) continue;
-            const int64_t units = (int64_t)tiles * sp;
-            double cost = (double)((units + cus - 1) / cus) * (loop * mi / 8.0 / sp + per_unit);
-            if (sp > 1) cost += 700.0 + (double)sp * p.M * p.N * 8.0 / 4.0e6 / 0.0166;  // fix-up launch + slab write / read at 4 TB/s
-            if (cost < best * 0.97) {  // prefer the earlier candidate (taller tile, fewer chunks) on near ties
-                best = cost;
-                *mi_out = mi;
-                *splits_out = sp;
+    *ni_out = 4;
+    for (int mi = 8; mi >= 4; mi -= 4)
+        for (int ni = 4; ni >= (no_narrow ? 4 : 3); --ni) {
+            if ((force_ni && ni != force_ni) || (force_mi && mi != force_mi)) continue;
+            const int tiles = ((p.N + ni * 64 - 1) / (ni * 64)) * ((p.M + mi * 32 - 1) / (mi * 32));
+            const double per_unit = (480.0 + 60.0 * mi) * (ni == 4 ? 1.0 : 1.1);  // prologue + epilogue of a work unit
+            const double unit_loop = loop * mi / 8.0 * (ni == 4 ? 1.0 : 0.75 * 1.06);
+            int64_t smax = 1;
+            if (p.splitk_ws && p.K % 128 == 0) {
+                smax = std::min<int64_t>(p.K / 256, p.splitk_ws_elems / ((int64_t)p.M * p.N));
+                smax = std::min<int64_t>(smax, 32);
+                // (a product too large for even one slab -- M x N beyond the workspace -- is still planned: until round 5 this
+                // came out as 0 candidates, i.e. always 256 x 256 tiles; QKV of 16 x 10 s ran 164 instead of 145 us for it)
+                smax = std::max<int64_t>(smax, 1);
+            }
+            for (int sp = 1; sp <= smax; ++sp) {
+                if ((p.K / 128) % sp) continue;
+                const int64_t units = (int64_t)tiles * sp;
+                double cost = (double)((units + cus - 1) / cus) * (unit_loop / sp + per_unit);
+                if (sp > 1) cost += 700.0 + (double)sp * p.M * p.N * 8.0 / 4.0e6 / 0.0166;  // fix-up launch + slab write / read at 4 TB/s
+                if (cost < best * 0.97) {  // prefer the earlier candidate (taller, wider tile, fewer chunks) on near ties
+                    best = cost;
+                    *mi_out = mi;
+                    *splits_out = sp;
+                    *ni_out = ni;
+                }
             }
         }
-    }
 }
 
 template <typename T, int NT>
 bool launch_gemm_pp(const GemmParams& p, hipStream_t stream) {
     if (!pp_eligible(NT, p)) return false;
-    int mi, splits;
-    pp_plan(NT, p, &mi, &splits);
-    if (mi == 8) launch_pp_tiles<T, NT, 8>(p, splits, stream);
-    else launch_pp_tiles<T, NT, 4>(p, splits, stream);
+    int mi, splits, ni;
+    pp_plan(NT, p, &mi, &splits, &ni);
+    if (mi == 8 && ni == 4) launch_pp_tiles<T, NT, 8, 4>(p, splits, stream);
+    else if (mi == 8) launch_pp_tiles<T, NT, 8, 3>(p, splits, stream);
+    else if (ni == 4) launch_pp_tiles<T, NT, 4, 4>(p, splits, stream);
+    else launch_pp_tiles<T, NT, 4, 3>(p, splits, stream);
     return true;
 }
 
@@ -340,8 +355,8 @@ void launch_gemm_t(const GemmParams& p, hipStream_t stream) {
 // the K chunks launch_gemm_t will use: the same decisions, without the launches
 int planned_splits(int NT, const GemmParams& p) {
     if (!dma_preferred_shape(NT, p) && pp_eligible(NT, p)) {
-        int mi, splits;
-        pp_plan(NT, p, &mi, &splits);
+        int mi, splits, ni;
+        pp_plan(NT, p, &mi, &splits, &ni);
         return splits;
     }
     const int shape = dma_tile_shape(NT, p, 1);

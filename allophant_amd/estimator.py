@@ -458,6 +458,8 @@ class Estimator:
 
     def graph_info(self) -> Tuple[int, int]:
         """(forward passes recorded into HIP graphs, passes replayed from one) so far -- ``amx_graph_info``."""
+        if _lib.AMX_ABI_VERSION < 5:
+            return 0, 0
         captures, replays = C.c_int64(0), C.c_int64(0)
         _lib.check(self._lib, self._handle, self._lib.amx_graph_info(self._handle, C.byref(captures), C.byref(replays)))
         return int(captures.value), int(replays.value)

@@ -9,7 +9,9 @@ import ctypes as C
 import os
 from typing import Optional
 
-AMX_ABI_VERSION = 5
+# AMX_ABI_OVERRIDE: developer switch for same-box A/B runs against a library built from an OLDER revision (tools/ab_build.sh):
+# ABI 5 added flags and entry points to ABI 4 without changing a struct, so an ABI-4 build runs under this binding
+AMX_ABI_VERSION = int(os.environ.get("AMX_ABI_OVERRIDE") or 5)
 AMX_MAX_CONV = 8
 AMX_MAX_DEPS = 64
 AMX_NAME_LEN = 48
@@ -97,8 +99,9 @@ def load() -> C.CDLL:
     lib.amx_forward.restype = i32
     lib.amx_synchronize.argtypes = [vp, vp]
     lib.amx_synchronize.restype = i32
-    lib.amx_graph_info.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
-    lib.amx_graph_info.restype = i32
+    if hasattr(lib, "amx_graph_info") or AMX_ABI_VERSION >= 5:  # (absent from an ABI-4 build under AMX_ABI_OVERRIDE)
+        lib.amx_graph_info.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
+        lib.amx_graph_info.restype = i32
     lib.amx_check_finite.argtypes = [vp, vp, C.POINTER(i64)]
     lib.amx_check_finite.restype = i32
     lib.amx_greedy_ctc.argtypes = [vp, vp, C.POINTER(i64), i32, i64, vp, vp, vp, vp, vp]

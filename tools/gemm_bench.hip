@@ -1,6 +1,6 @@
 // Developer micro-benchmark + self-check of the GEMM kernels of liballophant_amx (includes the translation unit directly so
-// that ablation macros apply).  Build:
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iallophant_amd/csrc -Iinclude -o build/gemm_bench tools/gemm_bench.hip
+// that ablation macros apply).  Build (-DAMX_DEVELOPER: the AMX_* A/B switches read the environment, e.g. AMX_PP_FORCE_NI=3):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DAMX_DEVELOPER -Iallophant_amd/csrc -Iinclude -o build/gemm_bench tools/gemm_bench.hip
 //   hipcc ... -DAMX_ABLATE_NO_EPI -o build/gemm_bench_noepi tools/gemm_bench.hip
 // Run:  build/gemm_bench check   (ping-pong kernel vs generic tile kernel on edge-case shapes)
 //       build/gemm_bench time    (model shapes of BASELINE config 2, both kernels, f16x3 and bf16)
@@ -309,7 +309,7 @@ int main(int argc, char** argv) {
     if (argc > 1 && !strcmp(argv[1], "small")) {
         // products of short batches (rows = frames of 1 x 3 s, 1 x 10 s, 4 x 10 s, 1 x 60 s): split-K against no split
         g_compare_nosplit = true;
-        const int rows[] = {149, 499, 1996, 2999, 7984};
+        const int rows[] = {149, 499, 1996, 2999, 3992, 7984};
         int precs[] = {PREC_F16X3, PREC_BF16};
         for (int prec : precs)
             for (int M : rows) {
@@ -350,6 +350,12 @@ int main(int argc, char** argv) {
             {"split generic gelu->planes", 149, 4096, 1024, 1, 0, 0, 1, 0, 0, 0, 0, 1.0f},
             {"split generic conv-like", 598, 512, 1536, 0, 0, 0, 0, 1, 0, 299, 1024, 1.0f},
             {"split generic qkv scatter", 499, 3072, 1024, 0, 0, 0, 0, 0, 1, 0, 0, 1.0f},
+            // shapes the plan gives 192-column tiles (NI = 3), and -- under AMX_PP_FORCE_NI=3 -- their N tails
+            {"192-wide qkv scatter 8 x 10 s", 3992, 3072, 1024, 0, 0, 0, 0, 0, 1, 0, 0, 1.0f},
+            {"192-wide qkv scatter 16 x 10 s", 7984, 3072, 512, 0, 0, 0, 0, 0, 1, 0, 0, 1.0f},
+            {"N tail f32 +res +mask", 2100, 640, 384, 0, 1, 1, 0, 1, 0, 0, 0, 0.5f},
+            {"N tail gelu->planes", 4000, 1088, 256, 1, 0, 0, 1, 0, 0, 0, 0, 1.0f},
+            {"N = 4 mod 192 f32 + planes", 2048, 580, 128, 0, 0, 0, 1, 1, 0, 0, 0, 1.0f},
         };
         int precs[] = {PREC_F16X3, PREC_BF16X3, PREC_F16, PREC_BF16};
         int bad = 0;
