@@ -66,6 +66,8 @@ struct amx_handle_s {
 
     // weights
     float *c0_w = nullptr, *c0_b = nullptr;
+    double* c0_stats = nullptr;  // conv layer 0 on the matrix pipe: fp64 mean / covariance of the rows [w_c, b_c] (amx_common.h)
+    float c0_wscale = 1.f;       // power of two its fp16 weight planes are built under
     // the variant of the wav2vec 2.0 encoder (amx_config ABI 4)
     bool gn = false;         // feat_extract_norm == "group": GroupNorm over time behind conv layer 0, no norm behind layers 1..
     bool stable = true;      // do_stable_layer_norm: pre-LN layers + final LayerNorm; false: post-LN layers
@@ -525,6 +527,28 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
                 if (hipDeviceSynchronize() != hipSuccess) { h->err = "pack_conv_w failed"; return bail(AMX_EHIP); }
             }
             c_in = C;
+        }
+        // conv layer 0 on the matrix pipe (LayerNorm variant, k = 10, C = 512): the LayerNorm statistics of a frame are a linear
+        // and a quadratic form of its 10 samples -- mean_c(w_c . x + b_c) = m . [x; 1], var_c = [x; 1]^T G [x; 1] with m / G the mean
+        // / covariance of the rows [w_c, b_c] over the channels -- tabulated here in fp64
+        if (!h->gn && conv0_mfma_eligible(C, cfg->conv_kernel[0], cfg->conv_stride[0])) {
+            const amx_tensor* wt = tm.get(AM + "feature_extractor.conv_layers.0.conv.weight");
+            const amx_tensor* bt = cfg->conv_bias ? tm.get(AM + "feature_extractor.conv_layers.0.conv.bias") : nullptr;
+            const int k0 = cfg->conv_kernel[0], dim = k0 + 1;
+            std::vector<double> table((size_t)dim + (size_t)dim * dim, 0.0), row(dim);
+            for (int ch = 0; ch < C; ++ch)
+                for (int j = 0; j < dim; ++j) table[j] += (j < k0 ? (double)wt->data[(size_t)ch * k0 + j] : (bt ? (double)bt->data[ch] : 0.0)) / C;
+            for (int ch = 0; ch < C; ++ch) {
+                for (int j = 0; j < dim; ++j) row[j] = (j < k0 ? (double)wt->data[(size_t)ch * k0 + j] : (bt ? (double)bt->data[ch] : 0.0)) - table[j];
+                for (int a = 0; a < dim; ++a)
+                    for (int b2 = 0; b2 < dim; ++b2) table[(size_t)dim + (size_t)a * dim + b2] += row[a] * row[b2] / C;
+            }
+            h->c0_stats = (double*)dev_alloc(h, table.size() * 8);
+            if (!h->c0_stats || hipMemcpy(h->c0_stats, table.data(), table.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
+                h->err = "device allocation failed";
+                return bail(AMX_ENOMEM);
+            }
+            h->c0_wscale = pack_scale({{wt, 1.f}});
         }
     }
     // ---- feature projection ----
@@ -1435,7 +1459,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         Timed t_(h, AMX_KC_CONV0);
         launch_conv0(prec, d_audio, (const int64_t*)d_len, (const float*)d_stats, N, L, (int)Ts[1], C, c.conv_kernel[0],
                      c.conv_stride[0], h->c0_w, h->conv_b[0], h->conv_g[0], h->conv_be[0], 1e-5f, c.do_normalize, actA,
-                     pln(h, rows1 * C), ragged ? 1 : 0, s);
+                     pln(h, rows1 * C), ragged ? 1 : 0, s, h->c0_stats, h->c0_wscale);
     }
     // ---- conv layers 1..n-1: implicit GEMM over overlapping channels-last windows, then LN + GELU rows ----
     void* cur = actA;

@@ -300,8 +300,14 @@ void launch_audio_stats(const float* audio, const int64_t* lengths, int N, int64
 // conv layer 0 (C_in = 1) + LayerNorm(C) + GELU, fused; writes planes [N*T1, C]
 void launch_conv0(int prec, const float* audio, const int64_t* lengths, const float* mean_rstd, int N, int64_t L, int T1,
                   int C, int k, int stride, const float* w /*[C,k]*/, const float* b, const float* gamma,
-                  const float* beta, float eps, int do_normalize, void* out, int64_t out_plane, int skip_padding, hipStream_t s);
+                  const float* beta, float eps, int do_normalize, void* out, int64_t out_plane, int skip_padding, hipStream_t s,
+                  const double* mfma_stats = nullptr, float w_scale = 1.f);
 // (skip_padding: frame blocks that start beyond an utterance's own frames are not computed -- ragged batches)
+// (mfma_stats: device table of CONV0_MFMA_STATS doubles for the matrix-pipe form of the kernel, conv0_mfma_eligible shapes:
+// the mean of the rows [w_c, b_c] over the channels (11) and their covariance (11 x 11, row-major), computed in fp64 at
+// amx_create; w_scale: the power of two the fp16 weight planes are built under.  Null: the VALU kernel.)
+constexpr int CONV0_MFMA_STATS = 11 + 121;
+bool conv0_mfma_eligible(int C, int k, int stride);
 // the group-norm feature extractor (feat_extract_norm = "group"): conv layer 0 + GroupNorm(C groups) over the T1 frames of the
 // padded length + GELU.  Two passes over the audio (the k-tap conv is recomputed, never stored): per-(utterance, channel)
 // fp64 statistics into `partial` (conv0_groupnorm_partial_bytes) -> scale / shift [N, C] -> the conv0 kernel with the affine

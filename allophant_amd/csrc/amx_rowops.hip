@@ -162,6 +162,17 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ au
             for (int u = 0; u < FPI; ++u)
 #pragma unroll
                 for (int i = 0; i < CP; ++i) acc[u][i] = b2[i];
+#ifdef AMX_C0_ABLATE_TAPS
+            // developer ablation (wrong results): the k-tap contraction reduced to ONE tap -- what the kernel would cost if the
+            // taps ran somewhere else (e.g. on the matrix pipe): an upper bound of what an MFMA form of them could save
+#pragma unroll
+            for (int u = 0; u < FPI; ++u) {
+                const float x = win[(f + u) * stride];
+                const f32x2 xx = {x, x};
+#pragma unroll
+                for (int i = 0; i < CP; ++i) acc[u][i] = w2[i][0] * xx + acc[u][i];
+            }
+#else
 #pragma unroll
             for (int j = 0; j < KW; ++j) {
 #pragma unroll
@@ -172,6 +183,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ au
                     for (int i = 0; i < CP; ++i) acc[u][i] = w2[i][j] * xx + acc[u][i];
                 }
             }
+#endif
             // channels beyond C carry zero weights and bias, so they add nothing to the sums (c0 + CPL <= C or lane idle)
             float mu[FPI], rs[FPI];
             if constexpr (!GN) {
@@ -290,6 +302,220 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ au
                         dst[i] = hi[i];
                         if (NT > 1) dst[out_plane + i] = lo[i];
                     }
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// conv layer 0 on the matrix pipe (round 5; k = 10, C = 512, LayerNorm variant -- every released wav2vec 2.0 / XLS-R shape).
+//
+// conv0_kernel above is VALU-bound (0.45 ms of its 0.57 ms per config-2 step without its stores): ~390 VALU instructions per
+// frame pair, of which the k-tap contraction is 28 % (measured: with ONE tap the kernel takes 0.41 ms, profiles/r05_conv0_*)
+// and the two 64-lane LayerNorm reductions another 20 %.  Here
+//   * the taps run as ONE v_mfma_f32_16x16x32_f16 per (16 channels x 16 frames): K = 32 holds the three split-precision terms of
+//     the 10-tap product side by side -- A row (channel) [w_hi(10) | w_lo(10) | w_hi(10) | 0 0], B column (frame)
+//     [x_hi(10) | x_hi(10) | x_lo(10) | 0 0] -- so hi.hi + lo.hi + hi.lo (2^-22 relative, fp32 accumulate) is a single MFMA on
+//     a pipe that idles in this kernel.  Both operands are fp16 planes whatever the handle's mode: the samples of a frame are
+//     scaled by an exact power of two (largest |x| of the frame into [512, 1024)) and the weights by one per tensor, so the lo
+//     planes stay normal numbers and silence is as accurate as speech (LayerNorm makes the result scale-free per frame);
+//   * the LayerNorm statistics need no pass over the channels: mean_c(w_c . x + b_c) = wbar . x + bbar and
+//     var_c(...) = x~^T G x~ with x~ = [x; 1] and G the 11 x 11 covariance of the rows [w_c, b_c] over the channels -- exact
+//     identities, evaluated per frame in fp64 from tables amx_create computes in fp64 (`stats`: 11 + 121 doubles), i.e. more
+//     accurate than the fp32 two-pass sums they replace, and 132 FMAs per frame instead of 2 x 512 + two butterflies;
+//   * a lane owns ONE frame and 4 consecutive channels per tile (MFMA output layout), so the normalisation is two packed FMAs
+//     with lane-constant factors; outputs go through a per-wave LDS patch and leave as whole 128-byte lines.
+// Workgroup = 128 frames (8 frame tiles) x 512 channels; wave w owns channels [128 w, 128 w + 128) with its weight fragments in
+// registers; the frame operands (8 KiB), scales and statistics of the 128 frames are built once per workgroup.
+// ----------------------------------------------------------------------------------------------------------------
+constexpr int C0M_FRAMES = 128, C0M_K = 10, C0M_C = 512;
+static_assert(CONV0_MFMA_STATS == 11 + 121, "stats table: mean of [w_c, b_c] over c (11 doubles), covariance G (11 x 11, row-major)");
+
+template <int NT>
+constexpr int c0m_rowb() { return (NT == 2 ? 512 : 256) + 16; }  // bytes of a staged frame row of one wave (+ 16: bank skew)
+inline size_t conv0_mfma_lds_bytes(int NT, int stride) {
+    const size_t win = ((size_t)(C0M_FRAMES * stride + C0M_K) * 4 + 15) & ~(size_t)15;
+    const size_t stage = (size_t)4 * 16 * (NT == 2 ? c0m_rowb<2>() : c0m_rowb<1>());
+    const size_t image = (size_t)C0M_C * 64;  // fp16 weight image [512][32], aliased with the staging patches
+    return win + 4 * C0M_FRAMES * 4 + (size_t)C0M_FRAMES * 64 + (stage > image ? stage : image);
+}
+
+template <typename T, int NT>
+__global__ __launch_bounds__(256, 2) void conv0_mfma_kernel(const float* __restrict__ audio, const int64_t* __restrict__ lengths,
+                                                            const float* __restrict__ mean_rstd, int64_t L, int T1, int stride,
+                                                            const float* __restrict__ w /*[512][10]*/, const float* __restrict__ b,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const double* __restrict__ stats, float w_scale, float eps,
+                                                            int do_normalize, T* __restrict__ out, int64_t out_plane,
+                                                            int skip_padding) {
+    typedef _Float16 h16;
+    typedef __attribute__((ext_vector_type(8))) _Float16 h16x8;
+    typedef typename Vec2<T>::type V2;
+    constexpr int ROWB = c0m_rowb<NT>();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n = blockIdx.y;
+    const int f0 = blockIdx.x * C0M_FRAMES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwin = C0M_FRAMES * stride + C0M_K;
+    const int64_t len = lengths[n];
+    if (skip_padding && (int64_t)f0 * stride + C0M_K > len && f0 > 0) return;  // (see conv0_kernel)
+    float* win = (float*)smem;
+    const int win_bytes = (nwin * 4 + 15) & ~15;
+    float* fr_a = (float*)(smem + win_bytes);          // per frame: acc -> conv value / sigma:  rstd / (2^s * w_scale)
+    float* fr_c = fr_a + C0M_FRAMES;                    //            - mean * rstd
+    float* fr_r = fr_c + C0M_FRAMES;                    //            rstd
+    unsigned char* bplanes = (unsigned char*)(fr_r + 2 * C0M_FRAMES);  // [8 frame tiles][64 MFMA lanes][16 B]
+    unsigned char* stage = bplanes + C0M_FRAMES * 64;   // per-wave output patches; first: the fp16 weight image [512][32]
+
+    // ---- the window of this workgroup's frames, input normalisation applied on load ----
+    const float mean = mean_rstd[2 * n], rstd_in = mean_rstd[2 * n + 1];
+    const int64_t s0 = (int64_t)f0 * stride;
+    for (int i = tid; i < nwin; i += 256) {
+        const int64_t pos = s0 + i;
+        float x = 0.f;
+        if (pos < L) {
+            x = audio[(int64_t)n * L + pos];
+            if (do_normalize) x = pos < len ? (x - mean) * rstd_in : 0.f;
+        }
+        win[i] = x;
+    }
+    // ---- weight image: row c = [w_hi(10) | w_lo(10) | w_hi(10) | 0 0] of w_c * w_scale as fp16 (two channels per thread) ----
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+        const int c = tid + 256 * rep;
+        h16 hi[C0M_K], lo[C0M_K];
+#pragma unroll
+        for (int j = 0; j < C0M_K; ++j) {
+            float v = w[c * C0M_K + j] * w_scale;
+            asm volatile("" : "+v"(v));
+            hi[j] = (h16)v;
+            asm volatile("" : "+v"(hi[j]));
+            lo[j] = (h16)(v - (float)hi[j]);
+        }
+        h16 row[32];
+#pragma unroll
+        for (int j = 0; j < C0M_K; ++j) { row[j] = hi[j]; row[10 + j] = lo[j]; row[20 + j] = hi[j]; }
+        row[30] = (h16)0.f; row[31] = (h16)0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            h16x8 v8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v8[e] = row[8 * q + e];
+            *(h16x8*)(stage + c * 64 + q * 16) = v8;
+        }
+    }
+    __syncthreads();
+    // ---- per frame (threads 0..127): power-of-two scale, fp64 LayerNorm statistics, the frame's B column ----
+    if (tid < C0M_FRAMES) {
+        const int f = tid;
+        float x[C0M_K];
+        float amax = 0.f;
+#pragma unroll
+        for (int j = 0; j < C0M_K; ++j) { x[j] = win[f * stride + j]; amax = fmaxf(amax, fabsf(x[j])); }
+        // exact power of two that puts the largest sample of the frame into [512, 1024) (1 for an all-zero / non-finite frame)
+        int e = 0;
+        if (amax > 0.f && amax < INFINITY) e = 9 - (((__builtin_bit_cast(int, amax) >> 23) & 255) - 127);
+        e = e < -100 ? -100 : (e > 120 ? 120 : e);
+        const float sc = __builtin_bit_cast(float, (127 + e) << 23), inv_sc = __builtin_bit_cast(float, (127 - e) << 23);
+        double xt[11];
+#pragma unroll
+        for (int j = 0; j < C0M_K; ++j) xt[j] = (double)x[j];
+        xt[10] = 1.0;
+        double mu = 0.0, var = 0.0;
+#pragma unroll
+        for (int a = 0; a < 11; ++a) {
+            mu = fma(stats[a], xt[a], mu);
+            double rowsum = 0.0;
+#pragma unroll
+            for (int c2 = 0; c2 < 11; ++c2) rowsum = fma(stats[11 + a * 11 + c2], xt[c2], rowsum);
+            var = fma(rowsum, xt[a], var);
+        }
+        if (!(var > 0.0)) var = 0.0;
+        const double rs = 1.0 / sqrt(var + (double)eps);
+        fr_r[f] = (float)rs;
+        fr_c[f] = (float)(-mu * rs);
+        fr_a[f] = (float)(rs * (double)inv_sc / (double)w_scale);
+        h16 hi[C0M_K], lo[C0M_K];
+#pragma unroll
+        for (int j = 0; j < C0M_K; ++j) {
+            float v = x[j] * sc;
+            asm volatile("" : "+v"(v));
+            hi[j] = (h16)v;
+            asm volatile("" : "+v"(hi[j]));
+            lo[j] = (h16)(v - (float)hi[j]);
+        }
+        h16 row[32];
+#pragma unroll
+        for (int j = 0; j < C0M_K; ++j) { row[j] = hi[j]; row[10 + j] = hi[j]; row[20 + j] = lo[j]; }
+        row[30] = (h16)0.f; row[31] = (h16)0.f;
+        const int ft = f >> 4, jj = f & 15;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {  // chunk q = the 8 K values MFMA lane (jj, group q) feeds
+            h16x8 v8;
+#pragma unroll
+            for (int e2 = 0; e2 < 8; ++e2) v8[e2] = row[8 * q + e2];
+            *(h16x8*)(bplanes + ((ft * 4 + q) * 16 + jj) * 16) = v8;
+        }
+    }
+    // ---- this wave's weight fragments (A operand: lane (i, g) = channel i of the tile, K 8g .. 8g + 7) and channel constants ----
+    const int li = lane & 15, g = lane >> 4;
+    h16x8 wf[8];
+    f32x2 b2[8][2], g2[8][2], be2[8][2];
+#pragma unroll
+    for (int tt = 0; tt < 8; ++tt) {
+        wf[tt] = *(const h16x8*)(stage + ((wave * 8 + tt) * 16 + li) * 64 + g * 16);
+        const int c = wave * 128 + tt * 16 + 4 * g;
+        const float4 bb = *(const float4*)(b + c), gg = *(const float4*)(gamma + c), ee = *(const float4*)(beta + c);
+        b2[tt][0] = f32x2{bb.x, bb.y}; b2[tt][1] = f32x2{bb.z, bb.w};
+        g2[tt][0] = f32x2{gg.x, gg.y}; g2[tt][1] = f32x2{gg.z, gg.w};
+        be2[tt][0] = f32x2{ee.x, ee.y}; be2[tt][1] = f32x2{ee.z, ee.w};
+    }
+    __syncthreads();  // frame columns and statistics are complete; the weight image is dead (its LDS becomes the patches)
+    unsigned char* patch = stage + wave * (16 * ROWB);
+    const bool o_il = plane_is_il<NT>(out_plane);
+    for (int ft = 0; ft < C0M_FRAMES / 16; ++ft) {
+        if (f0 + ft * 16 >= T1) break;  // (wave-uniform) nothing of this tile exists
+        const h16x8 xf = *(const h16x8*)(bplanes + (ft * 64 + lane) * 16);
+        const int f = ft * 16 + li;
+        const float a = fr_a[f], cc = fr_c[f], rr = fr_r[f];
+        const f32x2 a2 = {a, a}, c2 = {cc, cc}, r2 = {rr, rr};
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tt], xf, acc, 0, 0, 0);
+            V2 hi[2], lo[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const f32x2 v = {acc[2 * q], acc[2 * q + 1]};
+                // LayerNorm((v * inv_scale + b) ; mu, rstd) * gamma + beta with the per-frame factors folded: a = rstd * inv_scale
+                const f32x2 u = v * a2 + (b2[tt][q] * r2 + c2);
+                const f32x2 y = gelu_fast2(u * g2[tt][q] + be2[tt][q]);
+                lo[q] = V2{(T)0.f, (T)0.f};
+                split16x2<T, NT>(y, hi[q], lo[q]);
+            }
+            // channels co .. co + 3 of the wave's 128: the frame row as it lies in HBM (interleaved planes: [hi x 32 | lo x 32])
+            const int co = tt * 16 + 4 * g;
+            unsigned char* dst = patch + li * ROWB + (NT == 2 ? (co >> 5) * 128 + (co & 31) * 2 : co * 2);
+            union { V2 h[2]; uint64_t u; } ph, pl;
+            ph.h[0] = hi[0]; ph.h[1] = hi[1];
+            *(uint64_t*)dst = ph.u;
+            if (NT == 2) {
+                pl.h[0] = lo[0]; pl.h[1] = lo[1];
+                *(uint64_t*)(dst + 64) = pl.u;
+            }
+        }
+        // the wave's 16 x (128 channels) patch leaves as 16-byte pieces of whole lines (LDS operations of one wave complete in
+        // order: these reads see the writes above, and the next tile's writes follow them)
+        constexpr int CHUNKS_PER_ROW = (ROWB - 16) / 16, ROUNDS = 16 * CHUNKS_PER_ROW / 64;
+#pragma unroll
+        for (int q = 0; q < ROUNDS; ++q) {
+            const int id = q * 64 + lane, row = id / CHUNKS_PER_ROW, chunk = id - row * CHUNKS_PER_ROW;
+            const uint4 v = *(const uint4*)(patch + row * ROWB + chunk * 16);
+            const int t = f0 + ft * 16 + row;
+            if (t < T1) {
+                T* base = out + pidx(((int64_t)n * T1 + t) * C0M_C + wave * 128, o_il);
+                *(uint4*)((unsigned char*)base + chunk * 16) = v;
             }
         }
     }
@@ -1076,9 +1302,30 @@ static void conv0_launch_cpl(const float* audio, const int64_t* lengths, const f
 #undef C0_GO
 }
 
+bool conv0_mfma_eligible(int C, int k, int stride) {
+    static const bool off = dev_switch("AMX_NO_CONV0_MFMA");  // developer A/B switch: the VALU kernel
+    return !off && C == C0M_C && k == C0M_K && stride >= 1 && conv0_mfma_lds_bytes(2, stride) <= 64 * 1024;
+}
+
+template <typename T, int NT>
+static void conv0_mfma_launch(const float* audio, const int64_t* lengths, const float* mean_rstd, int N, int64_t L, int T1, int stride,
+                              const float* w, const float* b, const float* gamma, const float* beta, const double* stats, float w_scale,
+                              float eps, int do_normalize, void* out, int64_t out_plane, int skip_padding, hipStream_t s) {
+    dim3 grid((T1 + C0M_FRAMES - 1) / C0M_FRAMES, N);
+    hipLaunchKernelGGL((conv0_mfma_kernel<T, NT>), grid, dim3(256), conv0_mfma_lds_bytes(NT, stride), s, audio, lengths, mean_rstd, L, T1,
+                       stride, w, b, gamma, beta, stats, w_scale, eps, do_normalize, (T*)out, out_plane, skip_padding);
+}
+
 void launch_conv0(int prec, const float* audio, const int64_t* lengths, const float* mean_rstd, int N, int64_t L, int T1,
                   int C, int k, int stride, const float* w, const float* b, const float* gamma, const float* beta,
-                  float eps, int do_normalize, void* out, int64_t out_plane, int skip_padding, hipStream_t s) {
+                  float eps, int do_normalize, void* out, int64_t out_plane, int skip_padding, hipStream_t s,
+                  const double* mfma_stats, float w_scale) {
+    // (two planes: the patch image of the kernel is the interleaved layout)
+    if (mfma_stats && conv0_mfma_eligible(C, k, stride) && (prec_planes(prec) == 1 || out_plane == PLANE_IL)) {
+        AMX_DISPATCH(prec, (conv0_mfma_launch<T16, NT>(audio, lengths, mean_rstd, N, L, T1, stride, w, b, gamma, beta, mfma_stats, w_scale,
+                                                     eps, do_normalize, out, out_plane, skip_padding, s)));
+        return;
+    }
     if (k == 10) {
         AMX_DISPATCH(prec, (conv0_launch_cpl<T16, NT, 10, false>(audio, lengths, mean_rstd, N, L, T1, C, k, stride, w, b, gamma, beta,
                                                                 eps, do_normalize, out, out_plane, skip_padding, s)));
