@@ -164,6 +164,7 @@ struct amx_handle_s {
     struct GraphEntry {
         std::vector<int64_t> key;
         hipGraphExec_t exec = nullptr;
+        hipGraph_t graph = nullptr;  // the template stays alive as long as its instance (destroyed together)
         uint64_t last_use = 0;
     };
     static constexpr int GRAPH_CAP = 8;
@@ -1069,8 +1070,10 @@ extern "C" int amx_output_layout(amx_handle h, int N, int64_t L, amx_output_desc
 // forward
 // =================================================================================================================
 static void drop_graphs(amx_handle h) {
-    for (auto& g : h->graphs)
+    for (auto& g : h->graphs) {
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
     h->graphs.clear();
     h->graph_seen.clear();
 }
@@ -1082,6 +1085,7 @@ static int range_poll(amx_handle h, bool wait) {
     int64_t total = 0;
     int prev_count = 0;
     bool have_prev = false;
+    std::string readings;
     for (int i = 0; i < amx_handle_s::RANGE_SLOTS; ++i) {
         auto& sl = h->range[(h->range_next + i) % amx_handle_s::RANGE_SLOTS];  // oldest first
         if (!sl.pending) continue;
@@ -1097,13 +1101,14 @@ static int range_poll(amx_handle h, bool wait) {
         if (have_prev && !sl.cont) total += prev_count;
         prev_count = *sl.host;
         have_prev = true;
+        readings += (readings.empty() ? "" : ", ") + std::to_string(prev_count) + (sl.cont ? "c" : "");
     }
     if (have_prev) total += prev_count;
     if (total > 0)
         return fail(h, AMX_ERANGE, std::to_string(total) + " valid frame(s) of an EARLIER forward pass hold non-finite logits: an activation left the "
                                    "range of the 16-bit planes (fp16: |x| <= 65504) or the input was not finite; the outputs of that pass "
                                    "are not usable.  The bf16 planes (precision bf16x3) have the range of fp32; AMX_FLAG_NO_RANGE_CHECK "
-                                   "turns this report off");
+                                   "turns this report off (counts of the passes read, oldest first: " + readings + ")");
     return AMX_OK;
 }
 
@@ -1433,19 +1438,20 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     // =============================================================================================================
     auto enqueue = [&](hipStream_t s) -> int {
     // K/V/Q padding rows [T, Tp) must stay finite: re-zero when the geometry changes
+    // (zero fills inside a pass are kernels, never memsets: amx_rowops.hip, launch_zero)
     if (needs_qkv_zero) {
-        HIPCHK(h, hipMemsetAsync(qb, 0, qkv_bytes, s));
-        HIPCHK(h, hipMemsetAsync(kb, 0, qkv_bytes, s));
-        HIPCHK(h, hipMemsetAsync(vtb, 0, qkv_bytes, s));
+        launch_zero(qb, qkv_bytes, s);
+        launch_zero(kb, qkv_bytes, s);
+        launch_zero(vtb, qkv_bytes, s);
     }
     if (packed) {
         // rows [Mp, TpTot) of every head are read (never used) by the last key tile and query block: keep them finite
         const size_t row_b = 64 * 2, tail = (size_t)(TpTot - Mp) * row_b, pitch = (size_t)TpTot * row_b;
         for (void* buf : {qb, kb, vtb})  // the planes lie back to back: NT * H blocks of TpTot rows
-            HIPCHK(h, hipMemset2DAsync((char*)buf + (size_t)Mp * row_b, pitch, 0, tail, (size_t)NT * H, s));
+            launch_zero_2d((char*)buf + (size_t)Mp * row_b, pitch, tail, (size_t)NT * H, s);
     }
     // amx_check_finite reports on THIS forward pass; the later slices of one over-long batch (AMX_FLAG_CONTINUE) add up
-    if (!(flags & AMX_FLAG_CONTINUE)) HIPCHK(h, hipMemsetAsync(h->nonfinite, 0, 4, s));
+    if (!(flags & AMX_FLAG_CONTINUE)) launch_zero(h->nonfinite, 4, s);
     // ---- input normalisation statistics + conv layer 0 (fused norm + conv + LN + GELU) ----
     { Timed t_(h, AMX_KC_OTHER); launch_audio_stats(d_audio, (const int64_t*)d_len, N, L, (double*)d_partial, (float*)d_stats, c.do_normalize, s); }
     if (h->gn) {
@@ -1633,9 +1639,9 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             // frames take their pre-encoder rows (finite, as meaningless as any padded frame) and the valid ones are scattered in
             // (packed_early: the classifiers read packed rows, the copy is the packed stream as it is)
             if (packed_early) {
-                HIPCHK(h, hipMemcpyAsync(saved[l], hbuf, (size_t)Mp * D * 4, hipMemcpyDeviceToDevice, s));
+                launch_copy(saved[l], hbuf, (size_t)Mp * D * 4, s);  // (a kernel, not a memcpy node: see launch_zero)
             } else {
-                HIPCHK(h, hipMemcpyAsync(saved[l], packed ? hpad : hbuf, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s));
+                launch_copy(saved[l], packed ? hpad : hbuf, (size_t)M * D * 4, s);
                 if (packed) launch_pack_rows(saved[l], (float*)hbuf, (const int*)d_rowoff, (const int*)d_frames, N, T, D, true, s);
             }
         }
@@ -1704,7 +1710,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         stream_norm(h->fln_g, h->fln_b, Mh, pln(h, Mh * D), (float*)hfin);
     } else if (keep) {
         // post-LN: hidden_states[layers] = the stream as the last layer left it (hfin_rows); its planes are in xp already
-        HIPCHK(h, hipMemcpyAsync(hfin, hbuf, (size_t)Mh * D * 4, hipMemcpyDeviceToDevice, s));
+        launch_copy(hfin, hbuf, (size_t)Mh * D * 4, s);
     }
 
     // ---- hierarchical projection ----
@@ -1803,7 +1809,6 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
                     return erc;
                 }
                 if (end == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
-                    (void)hipGraphDestroy(graph);
                     if ((int)h->graphs.size() >= amx_handle_s::GRAPH_CAP) {
                         // evict the least recently used recording once nothing on the stream can still be running it
                         size_t lru = 0;
@@ -1811,12 +1816,14 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
                             if (h->graphs[i].last_use < h->graphs[lru].last_use) lru = i;
                         HIPCHK(h, hipStreamSynchronize(s));
                         (void)hipGraphExecDestroy(h->graphs[lru].exec);
+                        if (h->graphs[lru].graph) (void)hipGraphDestroy(h->graphs[lru].graph);
                         h->graphs.erase(h->graphs.begin() + (long)lru);
                     }
                     HIPCHK(h, hipGraphLaunch(exec, s));
                     amx_handle_s::GraphEntry entry;
                     entry.key = key;
                     entry.exec = exec;
+                    entry.graph = graph;
                     entry.last_use = ++h->graph_clock;
                     h->graphs.push_back(std::move(entry));
                     ++h->graph_captures;

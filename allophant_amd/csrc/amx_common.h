@@ -394,5 +394,9 @@ void launch_compose(int prec, const float* emb, int E, const int64_t* idx /*[P+1
                     int P1, int F, float scale, float* composed_f32 /*[P1,E]*/, void* dst, int64_t dst_plane, int64_t ldd,
                     hipStream_t s);
 void launch_scale_copy(const float* src, float* dst, int64_t n, float scale, hipStream_t s);
+// zero fills as kernels (a forward pass holds no hipMemset: see amx_rowops.hip); sizes / pitch multiples of 4 bytes
+void launch_zero(void* p, size_t bytes, hipStream_t s);
+void launch_zero_2d(void* base, size_t pitch, size_t width_bytes, size_t rows, hipStream_t s);
+void launch_copy(void* dst, const void* src, size_t bytes, hipStream_t s);
 
 }  // namespace amx

@@ -1484,6 +1484,61 @@ void launch_compose(int prec, const float* emb, int E, const int64_t* idx, int P
                                           scale, composed_f32, (T16*)dst, dst_plane, ldd));
 }
 
+// Zero fills and device copies of a forward pass as KERNELS: a pass holds no hipMemset / hipMemcpy.  A pass may be recorded into
+// a HIP graph, and on this runtime (ROCm 7.2) replays of a recorded pass -- once eager passes had run between them -- left
+// 0x01010101 in the non-finite frame counter that the pass's memset node zeroes (every other replay: one of the two recordings
+// of a caller that alternates between two output buffers; tools/debug_range2.py, profiles/r05_memset_node_replay.log).  Found by
+// the range report itself.  Two changes removed it, not separated: no memset / memcpy node in a pass (kernel nodes carry their
+// arguments by value), and the graph template now lives as long as its instance (amx_api.hip).  Sizes are multiples of 4 bytes,
+// pointers 4-byte aligned (callers: fp16 plane rows of 128 bytes, fp32 rows, one int counter).
+namespace {
+__global__ __launch_bounds__(256) void zero_fill_kernel(uint32_t* __restrict__ p, size_t words) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool aligned = ((uintptr_t)p & 15) == 0;
+    const size_t quads = aligned ? words / 4 : 0;
+    for (size_t q = i; q < quads; q += stride) ((uint4*)p)[q] = make_uint4(0, 0, 0, 0);
+    for (size_t w = quads * 4 + i; w < words; w += stride) p[w] = 0;
+}
+__global__ __launch_bounds__(256) void copy_words_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, size_t words) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool aligned = (((uintptr_t)dst | (uintptr_t)src) & 15) == 0;
+    const size_t quads = aligned ? words / 4 : 0;
+    for (size_t q = i; q < quads; q += stride) ((uint4*)dst)[q] = ((const uint4*)src)[q];
+    for (size_t w = quads * 4 + i; w < words; w += stride) dst[w] = src[w];
+}
+__global__ __launch_bounds__(256) void zero_fill_2d_kernel(unsigned char* __restrict__ base, size_t pitch, size_t width_words) {
+    uint32_t* row = (uint32_t*)(base + (size_t)blockIdx.y * pitch);
+    for (size_t w = (size_t)blockIdx.x * 256 + threadIdx.x; w < width_words; w += (size_t)gridDim.x * 256) row[w] = 0;
+}
+}  // namespace
+
+void launch_zero(void* p, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return;
+    const size_t words = bytes / 4;
+    size_t blocks = (words / 4 + 255) / 256 + 1;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (uint32_t*)p, words);
+}
+
+// device-to-device copy of a pass as a kernel, for the same reason (bytes a multiple of 4)
+void launch_copy(void* dst, const void* src, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return;
+    const size_t words = bytes / 4;
+    size_t blocks = (words / 4 + 255) / 256 + 1;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(copy_words_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (uint32_t*)dst, (const uint32_t*)src, words);
+}
+
+void launch_zero_2d(void* base, size_t pitch, size_t width_bytes, size_t rows, hipStream_t s) {
+    if (width_bytes == 0 || rows == 0) return;
+    const size_t words = width_bytes / 4;
+    size_t bx = (words + 255) / 256;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(zero_fill_2d_kernel, dim3((unsigned)bx, (unsigned)rows), dim3(256), 0, s, (unsigned char*)base, pitch, words);
+}
+
 void launch_scale_copy(const float* src, float* dst, int64_t n, float scale, hipStream_t s) {
     hipLaunchKernelGGL(scale_copy_kernel, dim3(grid_for(n)), dim3(256), 0, s, src, dst, n, scale);
 }

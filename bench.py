@@ -47,7 +47,7 @@ MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/f16 MFMA peak, /opt/skills/guides/MI355X
 HBM_PEAK_GBS = 8000.0
 MEASURED_MFMA_CEILING_TFLOPS = 2100.0  # 16x16x32 f16, two waves per SIMD (profiles/r02_mfma_only_ceiling.log)
 CONV0_PATTERN_STORE_GBS = 5660.0  # conv0's own store pattern without its arithmetic (tools/store_bw_probe.hip, profiles/r03_store_bw.log)
-TRAFFIC_FILES = ("r04_traffic.json", "r04b_traffic.json", "r03il_traffic.json", "r03_traffic.json", "r02_traffic.json")  # newest first; written by tools/collect_profiles.py
+TRAFFIC_FILES = ("r05_traffic.json", "r04_traffic.json", "r04b_traffic.json", "r03il_traffic.json", "r03_traffic.json", "r02_traffic.json")  # newest first; written by tools/collect_profiles.py
 
 
 # BASELINE.json configs this file can time on one GPU (config 3 = config 2 under --gpus N; config 1 is CPU plumbing):
@@ -331,6 +331,9 @@ def main():
                     help="N > 1: also time the step that gathers greedy CTC alignments of the phoneme output instead of log-probs")
     ap.add_argument("--no-ragged", action="store_true", help="N = 1: skip the informational ragged-batch leg")
     ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the weak-scaling leg (32 x 10 s per GPU)")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="enqueue every pass launch by launch (AMX_FLAG_NO_GRAPH) instead of replaying its HIP graph: the same kernels; "
+                         "used under rocprofv3 counter collection (tools/profile_bench.sh)")
     args = ap.parse_args()
     preset = CONFIG_PRESETS[args.config]
     if args.utterances is None:
@@ -383,11 +386,12 @@ def main():
         numbers.  `batch` is this rank's device-resident shard."""
         est = Estimator(spec, state, device, precision)
         # equal shards are established on the host below (shard_bounds of equal-length utterances): no per-step agreement
-        runner = parallel.DataParallelRunner(lambda b: est.predict(b, tfi, True), device, dst=0, verify_shapes=False) if use_dist else None
+        runner = parallel.DataParallelRunner(lambda b: est.predict(b, tfi, True, _no_graph=args.no_graph), device, dst=0,
+                                             verify_shapes=False) if use_dist else None
 
         def step(timing=False):
             if runner is None:
-                return est.predict(batch, tfi, True, _timing=timing)
+                return est.predict(batch, tfi, True, _timing=timing, _no_graph=args.no_graph)
             if timing:
                 est.predict(batch, tfi, True, _timing=True)
                 return None
@@ -635,13 +639,13 @@ def main():
         try:
             est = Estimator(spec, state, device, args.precision)
             host_audio = audio.pin_memory()
-            probe = est.predict(local, tfi, True)
+            probe = est.predict(local, tfi, True, _no_graph=args.no_graph)
             host_out = torch.empty(probe._flat.numel(), dtype=torch.float32).pin_memory()
             del probe
 
             def host_step():
                 dev = Batch(host_audio.to(device, non_blocking=True), lengths, global_batch.language_ids)
-                p = est.predict(dev, tfi, True)
+                p = est.predict(dev, tfi, True, _no_graph=args.no_graph)
                 host_out.copy_(p._flat, non_blocking=True)
                 torch.cuda.synchronize()
 
@@ -731,7 +735,7 @@ def main():
                     oracle_out, oracle_len = O.predict(audio[:1].contiguous(), lengths[:1].contiguous(), state, spec, tfi,
                                                        synthetic.category_offsets(spec), True)
                 est = Estimator(spec, state, device, args.precision)
-                pred = est.predict(local, tfi, True)  # rank 0's shard starts at utterance 0 of the global batch
+                pred = est.predict(local, tfi, True, _no_graph=args.no_graph)  # rank 0's shard starts at utterance 0 of the global batch
                 range_error = None
                 try:
                     est.check_finite()  # AMX_ERANGE: an activation left the fp16 planes (non-finite logits on a valid frame)

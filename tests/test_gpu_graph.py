@@ -144,3 +144,32 @@ def test_raw_logits_and_host_io_passes_through_graphs(amd, model):
     torch.cuda.synchronize()
     assert not torch.equal(logp._flat, want)
     assert torch.allclose(torch.log_softmax(raw.outputs["phoneme"], -1), logp.outputs["phoneme"], atol=1e-5)
+
+
+def test_replays_between_eager_bursts_stay_clean(amd, model):
+    """Regression (round 5): a recorded pass replayed after a burst of eager passes reported 0x01010101 "non-finite frames" in every
+    other replay -- a hipMemset NODE of the graph wrote the byte 0x01 instead of 0 on this runtime once other work had run in
+    between.  A pass holds no memset / memcpy node any more (zero fills and device copies are kernels).  The pattern that showed
+    it: unsynchronised bursts, alternating eager and recorded, two live output buffers; nothing may raise, every pass is the
+    eager bits."""
+    spec, est = model
+    tfi = synthetic.make_inventory(spec, 27, seed=0)
+    audio, lengths = synthetic.make_audio(4, 160000, seed=21)
+    batch = amd.Batch(audio.cuda(), lengths, torch.zeros(4, dtype=torch.long))
+    want = est.predict(batch, tfi, True, _no_graph=True)
+    torch.cuda.synchronize()
+    want = want._flat.clone()
+    for round_ in range(3):
+        for no_graph in (True, False):
+            held = []
+            for i in range(24):
+                pred = est.predict(batch, tfi, True, _no_graph=no_graph)  # raises FloatingPointError on a dirty counter
+                held = (held + [pred])[-2:]  # two output buffers alive: the allocator alternates between two addresses
+            torch.cuda.synchronize()
+            assert all(torch.equal(p._flat, want) for p in held), (round_, no_graph)
+            for _ in range(4):
+                torch.cuda.synchronize()
+                est.predict(batch, tfi, True, _no_graph=no_graph)
+            est.synchronize()
+    captured, replayed = est.graph_info()
+    assert replayed >= 40

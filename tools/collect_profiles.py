@@ -70,7 +70,7 @@ for arg in sys.argv[2:]:
         "source": f"profiles/{round_tag}_{precision}_pmc_hbm.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, "
                   "bench.py --steps 2)",
     }
-    conv0 = [v for k, v in merged.items() if "conv0_kernel" in k]
+    conv0 = [v for k, v in merged.items() if "conv0_kernel" in k or "conv0_mfma_kernel" in k]
     if conv0:
         f, w = per_dispatch(conv0)
         # conv0 reads fp32 audio with 4-byte-per-lane loads (FETCH_SIZE calibration for that width is not in the guide: the
