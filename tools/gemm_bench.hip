@@ -139,7 +139,7 @@ static double run_case(int prec, const Case& c, bool timing_only, double* us_pp,
         if (c.planes_out) { g.out_p = outp; g.out_plane = plane_of(prec, o_el); g.ldp = c.N; }
         if (c.qkv) {
             g.mode = 1; g.q = q; g.k = k; g.v = vt; g.qk_plane = qk_el; g.T = T; g.Tp = Tp; g.H = H; g.dh = dh;
-            g.row_len = row_len;
+            if (c.mask) g.row_len = row_len;  // (the model's QKV product carries no row mask: the branch-free scatter epilogue)
         }
         g_force_generic_gemm = variant == 1 && !g_compare_nosplit;
         if (variant == 0) { g.splitk_ws = g_splitk_ws; g.splitk_ws_elems = SPLITK_ELEMS; }
@@ -185,12 +185,18 @@ static double run_case(int prec, const Case& c, bool timing_only, double* us_pp,
                 size_t n = x.size() / 2 / NT;
                 // the output planes of a product are interleaved like its operands; Q / K / V (r >= 2) are separate planes
                 const bool il = NT > 1 && r == 1;
+                int shown = 0;
                 for (size_t i = 0; i < n; ++i) {
                     const size_t ph = (size_t)pidx((int64_t)i, il), pl = il ? ph + PLANE_IL : n + i;
                     double va = to_f32(prec, a[ph]), vb = to_f32(prec, b[ph]);
                     if (NT > 1) { va += to_f32(prec, a[pl]); vb += to_f32(prec, b[pl]); }
                     double e = fabs(va - vb) / (1.0 + fabs(vb));
                     if (!(e <= worst)) worst = (e == e) ? e : 1e30;
+                    if (getenv("GEMM_BENCH_VERBOSE") && !(e <= 0.05) && shown < 24) {  // developer diagnostic: where the outputs differ
+                        printf("      buffer %zu element %zu (row %zu, col %zu of %d): ping-pong %.5g generic %.5g\n", r, i,
+                               r == 1 ? i / c.N : i / 64, r == 1 ? i % c.N : i % 64, r == 1 ? c.N : 64, va, vb);
+                        ++shown;
+                    }
                 }
             }
         }
@@ -336,6 +342,7 @@ int main(int argc, char** argv) {
             {"dense f32 + planes (no bias act)", 1024, 256, 128, 0, 0, 0, 1, 1, 0, 0, 0, 1.0f},
             {"conv-like overlapping rows", 2800, 512, 384, 0, 0, 0, 0, 1, 0, 700, 256, 1.0f},
             {"qkv scatter", 1497, 384, 256, 0, 0, 0, 0, 0, 1, 0, 0, 1.0f},
+            {"qkv scatter + row mask", 1497, 384, 256, 0, 0, 1, 0, 0, 1, 0, 0, 1.0f},
             {"long K", 1100, 256, 4096, 0, 1, 0, 0, 1, 0, 0, 0, 1.0f},
             // enough tiles for the 256 x 256 kernel (the cases above run on 128 x 256 tiles)
             {"256-row tiles f32 +res +mask", 16000, 1024, 256, 0, 1, 1, 0, 1, 0, 0, 0, 1.0f},
@@ -345,6 +352,7 @@ int main(int argc, char** argv) {
             // split-K (few tiles): ping-pong kernel with K chunks, generic kernel with grid.z chunks, + fix-up epilogue
             {"split pp gelu->planes", 2000, 1024, 1024, 1, 0, 0, 1, 0, 0, 0, 0, 1.0f},
             {"split pp qkv scatter", 1996, 3072, 1024, 0, 0, 0, 0, 0, 1, 0, 0, 1.0f},
+            {"split pp qkv scatter + row mask", 1996, 3072, 1024, 0, 0, 1, 0, 0, 1, 0, 0, 1.0f},
             {"split pp f32 +res +mask +planes", 1300, 512, 2048, 0, 1, 1, 1, 1, 0, 0, 0, 0.25f},
             {"split generic f32 +res +mask, N%4", 300, 1022, 1024, 0, 1, 1, 0, 1, 0, 0, 0, 0.5f},
             {"split generic gelu->planes", 149, 4096, 1024, 1, 0, 0, 1, 0, 0, 0, 0, 1.0f},
