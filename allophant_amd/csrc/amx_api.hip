@@ -532,6 +532,8 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
         // conv layer 0 on the matrix pipe (LayerNorm variant, k = 10, C = 512): the LayerNorm statistics of a frame are a linear
         // and a quadratic form of its 10 samples -- mean_c(w_c . x + b_c) = m . [x; 1], var_c = [x; 1]^T G [x; 1] with m / G the mean
         // / covariance of the rows [w_c, b_c] over the channels -- tabulated here in fp64
+        if (conv0_mfma_eligible(C, cfg->conv_kernel[0], cfg->conv_stride[0]))
+            h->c0_wscale = pack_scale({{tm.get(AM + "feature_extractor.conv_layers.0.conv.weight"), 1.f}});
         if (!h->gn && conv0_mfma_eligible(C, cfg->conv_kernel[0], cfg->conv_stride[0])) {
             const amx_tensor* wt = tm.get(AM + "feature_extractor.conv_layers.0.conv.weight");
             const amx_tensor* bt = cfg->conv_bias ? tm.get(AM + "feature_extractor.conv_layers.0.conv.bias") : nullptr;
@@ -1460,7 +1462,8 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         Timed t_(h, AMX_KC_CONV0);
         launch_conv0_groupnorm(prec, d_audio, (const int64_t*)d_len, (const float*)d_stats, N, L, (int)Ts[1], C, c.conv_kernel[0],
                                c.conv_stride[0], h->c0_w, h->conv_b[0], h->conv_g[0], h->conv_be[0], 1e-5f, c.do_normalize,
-                               (double*)gn_partial, (float*)gn_scale, (float*)gn_shift, actA, pln(h, rows1 * C), ragged ? 1 : 0, s);
+                               (double*)gn_partial, (float*)gn_scale, (float*)gn_shift, actA, pln(h, rows1 * C), ragged ? 1 : 0, s,
+                               conv0_mfma_eligible(C, c.conv_kernel[0], c.conv_stride[0]) ? h->c0_wscale : 0.f);
     } else {
         Timed t_(h, AMX_KC_CONV0);
         launch_conv0(prec, d_audio, (const int64_t*)d_len, (const float*)d_stats, N, L, (int)Ts[1], C, c.conv_kernel[0],

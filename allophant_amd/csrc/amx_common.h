@@ -318,7 +318,10 @@ size_t conv0_window_lds_bytes(int k, int stride, int group_norm);
 void launch_conv0_groupnorm(int prec, const float* audio, const int64_t* lengths, const float* mean_rstd, int N, int64_t L, int T1,
                             int C, int k, int stride, const float* w, const float* b, const float* gamma, const float* beta,
                             float eps, int do_normalize, double* partial, float* scale, float* shift, void* out, int64_t out_plane,
-                            int skip_padding, hipStream_t s);
+                            int skip_padding, hipStream_t s, float mfma_w_scale = 0.f);
+// (mfma_w_scale > 0 and a conv0_mfma_eligible shape: GroupNorm statistics from the utterance's 10 x 10 sample covariance in fp64
+// -- no second evaluation of the convolution -- and the apply pass on the matrix pipe; the power of two is that of the fp16
+// weight planes)
 // rows of the padded [N, T, D] fp32 matrix <-> rows of the packed [sum(frame_len), D] matrix (utterance n at row_off[n]);
 // only rows t < frame_len[n] move
 void launch_pack_rows(const float* padded, float* packed, const int* row_off, const int* frame_len, int N, int T, int D, bool unpack,

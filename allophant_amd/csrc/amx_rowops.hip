@@ -340,7 +340,9 @@ inline size_t conv0_mfma_lds_bytes(int NT, int stride) {
     return win + 4 * C0M_FRAMES * 4 + (size_t)C0M_FRAMES * 64 + (stage > image ? stage : image);
 }
 
-template <typename T, int NT>
+// GN (the group-norm feature extractor): `gamma` / `beta` are the per-(utterance, channel) scale and shift [N, C] of the GroupNorm
+// over time (conv0_gn_cov_final_kernel), y = (conv + b) * scale + shift: no per-frame statistics, `stats` unused.
+template <typename T, int NT, bool GN>
 __global__ __launch_bounds__(256, 2) void conv0_mfma_kernel(const float* __restrict__ audio, const int64_t* __restrict__ lengths,
                                                             const float* __restrict__ mean_rstd, int64_t L, int T1, int stride,
                                                             const float* __restrict__ w /*[512][10]*/, const float* __restrict__ b,
@@ -360,6 +362,7 @@ __global__ __launch_bounds__(256, 2) void conv0_mfma_kernel(const float* __restr
     const int nwin = C0M_FRAMES * stride + C0M_K;
     const int64_t len = lengths[n];
     if (skip_padding && (int64_t)f0 * stride + C0M_K > len && f0 > 0) return;  // (see conv0_kernel)
+    if (GN) { gamma += (int64_t)n * C0M_C; beta += (int64_t)n * C0M_C; }
     float* win = (float*)smem;
     const int win_bytes = (nwin * 4 + 15) & ~15;
     float* fr_a = (float*)(smem + win_bytes);          // per frame: acc -> conv value / sigma:  rstd / (2^s * w_scale)
@@ -418,24 +421,30 @@ __global__ __launch_bounds__(256, 2) void conv0_mfma_kernel(const float* __restr
         if (amax > 0.f && amax < INFINITY) e = 9 - (((__builtin_bit_cast(int, amax) >> 23) & 255) - 127);
         e = e < -100 ? -100 : (e > 120 ? 120 : e);
         const float sc = __builtin_bit_cast(float, (127 + e) << 23), inv_sc = __builtin_bit_cast(float, (127 - e) << 23);
-        double xt[11];
+        if constexpr (GN) {
+            fr_r[f] = 1.f;
+            fr_c[f] = 0.f;
+            fr_a[f] = inv_sc / w_scale;  // (both exact powers of two)
+        } else {
+            double xt[11];
 #pragma unroll
-        for (int j = 0; j < C0M_K; ++j) xt[j] = (double)x[j];
-        xt[10] = 1.0;
-        double mu = 0.0, var = 0.0;
+            for (int j = 0; j < C0M_K; ++j) xt[j] = (double)x[j];
+            xt[10] = 1.0;
+            double mu = 0.0, var = 0.0;
 #pragma unroll
-        for (int a = 0; a < 11; ++a) {
-            mu = fma(stats[a], xt[a], mu);
-            double rowsum = 0.0;
+            for (int a = 0; a < 11; ++a) {
+                mu = fma(stats[a], xt[a], mu);
+                double rowsum = 0.0;
 #pragma unroll
-            for (int c2 = 0; c2 < 11; ++c2) rowsum = fma(stats[11 + a * 11 + c2], xt[c2], rowsum);
-            var = fma(rowsum, xt[a], var);
+                for (int c2 = 0; c2 < 11; ++c2) rowsum = fma(stats[11 + a * 11 + c2], xt[c2], rowsum);
+                var = fma(rowsum, xt[a], var);
+            }
+            if (!(var > 0.0)) var = 0.0;
+            const double rs = 1.0 / sqrt(var + (double)eps);
+            fr_r[f] = (float)rs;
+            fr_c[f] = (float)(-mu * rs);
+            fr_a[f] = (float)(rs * (double)inv_sc / (double)w_scale);
         }
-        if (!(var > 0.0)) var = 0.0;
-        const double rs = 1.0 / sqrt(var + (double)eps);
-        fr_r[f] = (float)rs;
-        fr_c[f] = (float)(-mu * rs);
-        fr_a[f] = (float)(rs * (double)inv_sc / (double)w_scale);
         h16 hi[C0M_K], lo[C0M_K];
 #pragma unroll
         for (int j = 0; j < C0M_K; ++j) {
@@ -470,6 +479,10 @@ __global__ __launch_bounds__(256, 2) void conv0_mfma_kernel(const float* __restr
         b2[tt][0] = f32x2{bb.x, bb.y}; b2[tt][1] = f32x2{bb.z, bb.w};
         g2[tt][0] = f32x2{gg.x, gg.y}; g2[tt][1] = f32x2{gg.z, gg.w};
         be2[tt][0] = f32x2{ee.x, ee.y}; be2[tt][1] = f32x2{ee.z, ee.w};
+        if constexpr (GN) {  // (conv + b) * scale + shift = conv * scale + (b * scale + shift)
+            be2[tt][0] = b2[tt][0] * g2[tt][0] + be2[tt][0];
+            be2[tt][1] = b2[tt][1] * g2[tt][1] + be2[tt][1];
+        }
     }
     __syncthreads();  // frame columns and statistics are complete; the weight image is dead (its LDS becomes the patches)
     unsigned char* patch = stage + wave * (16 * ROWB);
@@ -489,7 +502,7 @@ __global__ __launch_bounds__(256, 2) void conv0_mfma_kernel(const float* __restr
             for (int q = 0; q < 2; ++q) {
                 const f32x2 v = {acc[2 * q], acc[2 * q + 1]};
                 // LayerNorm((v * inv_scale + b) ; mu, rstd) * gamma + beta with the per-frame factors folded: a = rstd * inv_scale
-                const f32x2 u = v * a2 + (b2[tt][q] * r2 + c2);
+                const f32x2 u = GN ? v * a2 : v * a2 + (b2[tt][q] * r2 + c2);
                 const f32x2 y = gelu_fast2(u * g2[tt][q] + be2[tt][q]);
                 lo[q] = V2{(T)0.f, (T)0.f};
                 split16x2<T, NT>(y, hi[q], lo[q]);
@@ -701,6 +714,117 @@ __global__ void conv0_gn_final_kernel(const double* __restrict__ partial, int bl
     const double sc = (double)gamma[c] * rs;
     scale[i] = (float)sc;
     shift[i] = (float)((double)beta[c] - mean * sc);
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// GroupNorm statistics without recomputing the convolution (round 5; k = 10, the conv0_mfma_kernel shapes).  The conv output of
+// channel c at frame t is w_c . x_t + b_c with x_t the frame's 10 (normalised) samples, so over the T1 frames of the padded length
+//   mean_t = w_c . xbar + b_c,    var_t = w_c^T Cov w_c,    xbar = mean_t x_t,  Cov = mean_t x_t x_t^T - xbar xbar^T  (10 x 10)
+// -- one pass over the audio for 10 + 55 sums in fp64 (conv0_gn_cov_kernel), then 110 fp64 FMAs per (utterance, channel)
+// (conv0_gn_cov_final_kernel) instead of a second evaluation of every conv output.  Deterministic: block partials in fixed
+// order, tree reductions of fixed shape.
+// ----------------------------------------------------------------------------------------------------------------
+constexpr int GNC_FRAMES = 2048;   // frames per workgroup
+constexpr int GNC_SUMS = 10 + 55;  // S1[j], S2[a <= b]
+
+__global__ __launch_bounds__(256) void conv0_gn_cov_kernel(const float* __restrict__ audio, const int64_t* __restrict__ lengths,
+                                                           const float* __restrict__ mean_rstd, int64_t L, int T1, int stride,
+                                                           int do_normalize, double* __restrict__ partial /*[N][blocks][65]*/) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* win = (float*)smem;
+    const int n = blockIdx.y, blk = blockIdx.x;
+    const int f0 = blk * GNC_FRAMES;
+    const int frames = min(GNC_FRAMES, T1 - f0);
+    const int nwin = (frames - 1) * stride + C0M_K;
+    const int64_t len = lengths[n];
+    const float mean = mean_rstd[2 * n], rstd = mean_rstd[2 * n + 1];
+    const int64_t s0 = (int64_t)f0 * stride;
+    for (int i = threadIdx.x; i < nwin; i += 256) {
+        const int64_t pos = s0 + i;
+        float x = 0.f;
+        if (pos < L) {
+            x = audio[(int64_t)n * L + pos];
+            if (do_normalize) x = pos < len ? (x - mean) * rstd : 0.f;
+        }
+        win[i] = x;
+    }
+    __syncthreads();
+    double acc[GNC_SUMS];
+#pragma unroll
+    for (int i = 0; i < GNC_SUMS; ++i) acc[i] = 0.0;
+    for (int f = threadIdx.x; f < frames; f += 256) {
+        double x[C0M_K];
+#pragma unroll
+        for (int j = 0; j < C0M_K; ++j) x[j] = (double)win[f * stride + j];
+        int p = C0M_K;
+#pragma unroll
+        for (int a = 0; a < C0M_K; ++a) {
+            acc[a] += x[a];
+#pragma unroll
+            for (int b2 = a; b2 < C0M_K; ++b2) { acc[p] = fma(x[a], x[b2], acc[p]); ++p; }
+        }
+    }
+    // wave totals (xor tree), then the four waves in order
+#pragma unroll
+    for (int i = 0; i < GNC_SUMS; ++i) {
+        double v = acc[i];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+        acc[i] = v;
+    }
+    __syncthreads();  // the window is dead: its LDS takes the wave totals
+    double* red = (double*)smem;  // [4][65]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < GNC_SUMS; ++i) red[wave * GNC_SUMS + i] = acc[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < GNC_SUMS) {
+        const double v = ((red[threadIdx.x] + red[GNC_SUMS + threadIdx.x]) + red[2 * GNC_SUMS + threadIdx.x]) + red[3 * GNC_SUMS + threadIdx.x];
+        partial[((int64_t)n * gridDim.x + blk) * GNC_SUMS + threadIdx.x] = v;
+    }
+}
+
+// one workgroup of 512 threads per utterance: totals of the block partials -> xbar, Cov; thread c -> scale / shift of channel c
+__global__ __launch_bounds__(512) void conv0_gn_cov_final_kernel(const double* __restrict__ partial, int blocks, int T1,
+                                                                 const float* __restrict__ w /*[512][10]*/, const float* __restrict__ b,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                                 float* __restrict__ scale, float* __restrict__ shift) {
+    __shared__ double tot[GNC_SUMS], xbar[C0M_K], cov[C0M_K][C0M_K];
+    const int n = blockIdx.x, c = threadIdx.x;
+    if (c < GNC_SUMS) {
+        double v = 0.0;
+        for (int blk = 0; blk < blocks; ++blk) v += partial[((int64_t)n * blocks + blk) * GNC_SUMS + c];
+        tot[c] = v;
+    }
+    __syncthreads();
+    if (c < C0M_K) xbar[c] = tot[c] / (double)T1;
+    __syncthreads();
+    if (c < C0M_K * C0M_K) {
+        const int a = c / C0M_K, b2 = c % C0M_K, lo = a < b2 ? a : b2, hi = a < b2 ? b2 : a;
+        // index of (lo, hi) in the upper-triangular order of conv0_gn_cov_kernel
+        const int p = C0M_K + lo * C0M_K - lo * (lo - 1) / 2 + (hi - lo);
+        cov[a][b2] = tot[p] / (double)T1 - xbar[a] * xbar[b2];
+    }
+    __syncthreads();
+    double wr[C0M_K];
+#pragma unroll
+    for (int j = 0; j < C0M_K; ++j) wr[j] = (double)w[c * C0M_K + j];
+    double mean = (double)b[c], var = 0.0;
+#pragma unroll
+    for (int a = 0; a < C0M_K; ++a) {
+        mean = fma(wr[a], xbar[a], mean);
+        double rowsum = 0.0;
+#pragma unroll
+        for (int b2 = 0; b2 < C0M_K; ++b2) rowsum = fma(cov[a][b2], wr[b2], rowsum);
+        var = fma(rowsum, wr[a], var);
+    }
+    if (!(var > 0.0)) var = 0.0;  // biased variance, like torch.nn.GroupNorm
+    const double rs = 1.0 / sqrt(var + (double)eps);
+    const double sc = (double)gamma[c] * rs;
+    scale[(int64_t)n * C0M_C + c] = (float)sc;
+    shift[(int64_t)n * C0M_C + c] = (float)((double)beta[c] - mean * sc);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -1307,12 +1431,12 @@ bool conv0_mfma_eligible(int C, int k, int stride) {
     return !off && C == C0M_C && k == C0M_K && stride >= 1 && conv0_mfma_lds_bytes(2, stride) <= 64 * 1024;
 }
 
-template <typename T, int NT>
+template <typename T, int NT, bool GN = false>
 static void conv0_mfma_launch(const float* audio, const int64_t* lengths, const float* mean_rstd, int N, int64_t L, int T1, int stride,
                               const float* w, const float* b, const float* gamma, const float* beta, const double* stats, float w_scale,
                               float eps, int do_normalize, void* out, int64_t out_plane, int skip_padding, hipStream_t s) {
     dim3 grid((T1 + C0M_FRAMES - 1) / C0M_FRAMES, N);
-    hipLaunchKernelGGL((conv0_mfma_kernel<T, NT>), grid, dim3(256), conv0_mfma_lds_bytes(NT, stride), s, audio, lengths, mean_rstd, L, T1,
+    hipLaunchKernelGGL((conv0_mfma_kernel<T, NT, GN>), grid, dim3(256), conv0_mfma_lds_bytes(NT, stride), s, audio, lengths, mean_rstd, L, T1,
                        stride, w, b, gamma, beta, stats, w_scale, eps, do_normalize, (T*)out, out_plane, skip_padding);
 }
 
@@ -1344,13 +1468,27 @@ size_t conv0_window_lds_bytes(int k, int stride, int group_norm) {
 }
 
 size_t conv0_groupnorm_partial_bytes(int N, int T1, int C) {
-    return (size_t)N * ((T1 + GN_FRAMES - 1) / GN_FRAMES) * C * 2 * sizeof(double);
+    const size_t recompute = (size_t)N * ((T1 + GN_FRAMES - 1) / GN_FRAMES) * C * 2 * sizeof(double);
+    const size_t covariance = (size_t)N * ((T1 + GNC_FRAMES - 1) / GNC_FRAMES) * GNC_SUMS * sizeof(double);
+    return recompute > covariance ? recompute : covariance;
 }
 
 void launch_conv0_groupnorm(int prec, const float* audio, const int64_t* lengths, const float* mean_rstd, int N, int64_t L, int T1,
                             int C, int k, int stride, const float* w, const float* b, const float* gamma, const float* beta,
                             float eps, int do_normalize, double* partial, float* scale, float* shift, void* out, int64_t out_plane,
-                            int skip_padding, hipStream_t s) {
+                            int skip_padding, hipStream_t s, float mfma_w_scale) {
+    // wav2vec 2.0 shape: statistics from the utterance's sample covariance (no second evaluation of the convolution), the
+    // apply pass on the matrix pipe (conv0_mfma_kernel<GN>)
+    const size_t cov_lds = (size_t)((GNC_FRAMES - 1) * stride + C0M_K) * sizeof(float);
+    if (mfma_w_scale > 0.f && conv0_mfma_eligible(C, k, stride) && (prec_planes(prec) == 1 || out_plane == PLANE_IL) && cov_lds <= 64 * 1024) {
+        const int cblocks = (T1 + GNC_FRAMES - 1) / GNC_FRAMES;
+        hipLaunchKernelGGL(conv0_gn_cov_kernel, dim3(cblocks, N), dim3(256), cov_lds, s, audio, lengths, mean_rstd, L, T1, stride, do_normalize,
+                           partial);
+        hipLaunchKernelGGL(conv0_gn_cov_final_kernel, dim3(N), dim3(512), 0, s, partial, cblocks, T1, w, b, gamma, beta, eps, scale, shift);
+        AMX_DISPATCH(prec, (conv0_mfma_launch<T16, NT, true>(audio, lengths, mean_rstd, N, L, T1, stride, w, b, scale, shift, nullptr,
+                                                           mfma_w_scale, eps, do_normalize, out, out_plane, skip_padding, s)));
+        return;
+    }
     const int blocks = (T1 + GN_FRAMES - 1) / GN_FRAMES;
     const size_t lds = (size_t)((GN_FRAMES - 1) * stride + k) * sizeof(float);
     static const bool plain_stats = dev_switch("AMX_GN_PLAIN_STATS");  // developer A/B switch

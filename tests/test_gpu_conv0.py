@@ -133,3 +133,36 @@ def test_first_layer_alone_matches_fp32_to_rounding(amd):
     print(f"[conv0 mfma] first layer vs fp64 evaluation: max abs {worst:.3g}")
     assert worst < 2e-5, worst
     est.close()
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "bf16x3"])
+def test_group_norm_first_layer_on_hard_audio_against_oracle(amd, precision):
+    """The group-norm family (wav2vec2-base shape): GroupNorm statistics from the utterance's 10 x 10 sample covariance
+    (``conv0_gn_cov_kernel``: the convolution is not evaluated a second time) and the apply pass on the matrix pipe
+    (``conv0_mfma_kernel<GN>``), on the same adversarial audio; the statistics run over every frame of the PADDED length
+    (transformers' Wav2Vec2GroupNormConvLayer normalises the padded batch tensor), so the ragged tail matters."""
+    from oracle import allophant_oracle as O
+
+    enc = S.wav2vec2_base_encoder()
+    enc["layers"] = 1
+    spec = S.multitask_spec(enc, ["syllabic", "long"], allophone_layer=True)
+    spec["shared_phones"] = 80
+    state = synthetic.make_state_dict(spec, seed=23)
+    tfi = synthetic.make_inventory(spec, 27, seed=23)
+    audio, lengths = _hard_audio(6, 40000, seed=78)
+    ref, ref_len, inter = O.predict(audio, lengths, state, spec, tfi, synthetic.category_offsets(spec), keep_intermediates=True)
+    est = amd.Estimator(spec, state, "cuda:0", precision)
+    pred = est.predict(amd.Batch(audio.cuda(), lengths, torch.zeros(6, dtype=torch.long)), tfi, True, _keep_hidden=True)
+    est.check_finite()
+    conv = est.debug_fetch("conv")
+    T = conv.shape[1]
+    worst_conv = float((conv - inter["conv_out"]).abs().max())  # no attention mask in this family: every padded frame counts
+    print(f"[conv0 mfma, group norm] {precision}: conv extractor output max abs {worst_conv:.3g}")
+    assert worst_conv < 1e-3, worst_conv
+    worst = 0.0
+    for name, expected in ref.items():
+        got = pred.outputs[name].cpu()
+        for i, t in enumerate(ref_len.tolist()):
+            worst = max(worst, float((got[:t, i] - expected[:t, i]).abs().max()))
+    assert worst < 1e-3, worst
+    est.close()
