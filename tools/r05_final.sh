@@ -4,7 +4,7 @@
 # 4 / 5 and of the wav2vec2-base family, and the geometry sweep of this tree against the round-4 library
 mkdir -p gpurun_out
 O=gpurun_out
-(timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -6) > $O/r05_gpu_suite.log
+(timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | grep -v "version\|Hostname\|Librccl" | tail -8) > $O/r05_gpu_suite.log
 bash tools/profile_bench.sh r05_f16x3 --precision f16x3 > $O/r05_profile_f16x3.log 2>&1
 bash tools/profile_bench.sh r05_bf16 --precision bf16 > $O/r05_profile_bf16.log 2>&1
 python tools/collect_profiles.py r05 f16x3:prof_r05_f16x3 bf16:prof_r05_bf16 > $O/r05_collect.log 2>&1
@@ -18,6 +18,13 @@ rm -f $O/r05_geometry_sweep_final.log
 (timeout 500 python tools/geometry_sweep.py f16x3 $G 2>&1 | grep -v amdgpu.ids | sed 's/^/this tree    : /') >> $O/r05_geometry_sweep_final.log
 (AMX_ABI_OVERRIDE=4 AMX_LIB_PATH=$PWD/build/ab/r04.so timeout 500 python tools/geometry_sweep.py f16x3 $G 2>&1 | grep -v amdgpu.ids | sed 's/^/round-4 lib   : /') >> $O/r05_geometry_sweep_final.log
 (timeout 500 python tools/geometry_sweep.py f16x3 $G 2>&1 | grep -v amdgpu.ids | sed 's/^/this tree    : /') >> $O/r05_geometry_sweep_final.log
+# bitwise reproducibility of repeated passes (graph replays included: the packed form goes through predict() as a caller would)
+rm -f $O/r05_race_screen.log
+for g in "1 3" "4 10" "32 10" "8 60" "2 25"; do
+  set -- $g
+  (STRESS_N=$1 STRESS_SECONDS=$2 STRESS_ITERS=20 timeout 600 python tools/stress_repro.py 2>&1 | grep -v amdgpu.ids | tail -3) >> $O/r05_race_screen.log
+  (STRESS_N=$1 STRESS_SECONDS=$2 STRESS_ITERS=20 STRESS_PACKED=1 timeout 600 python tools/stress_repro.py 2>&1 | grep -v amdgpu.ids | tail -3) >> $O/r05_race_screen.log
+done
 python - <<'PY'
 import json
 for name in ("r05_bench_line", "r05_bench_config4", "r05_bench_config5", "r05_bench_w2v2base"):
@@ -29,4 +36,4 @@ for name in ("r05_bench_line", "r05_bench_config4", "r05_bench_config5", "r05_be
     except Exception as e:
         print(name, "ERROR", e)
 PY
-cat $O/r05_gpu_suite.log $O/r05_collect.log; cut -c1-200 $O/r05_geometry_sweep_final.log; tail -3 $O/r05_bench_stderr.log
+cat $O/r05_gpu_suite.log $O/r05_collect.log $O/r05_race_screen.log; cut -c1-200 $O/r05_geometry_sweep_final.log; tail -3 $O/r05_bench_stderr.log
