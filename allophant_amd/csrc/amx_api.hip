@@ -186,6 +186,7 @@ struct amx_handle_s {
     static constexpr int RANGE_SLOTS = 8;
     RangeSlot range[RANGE_SLOTS];
     int range_next = 0;
+    int64_t range_carry = 0;  // count of a slot that had to be reused before any call had read it
     // last forward geometry
     int last_N = 0;
     bool qkv_dirty = false;
@@ -1106,6 +1107,8 @@ static int range_poll(amx_handle h, bool wait) {
         readings += (readings.empty() ? "" : ", ") + std::to_string(prev_count) + (sl.cont ? "c" : "");
     }
     if (have_prev) total += prev_count;
+    total += h->range_carry;
+    h->range_carry = 0;
     if (total > 0)
         return fail(h, AMX_ERANGE, std::to_string(total) + " valid frame(s) of an EARLIER forward pass hold non-finite logits: an activation left the "
                                    "range of the 16-bit planes (fp16: |x| <= 65504) or the input was not finite; the outputs of that pass "
@@ -1122,13 +1125,10 @@ static int range_record(amx_handle h, bool cont, hipStream_t s) {
         HIPCHK(h, hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
     }
     if (sl.pending) {
-        // RANGE_SLOTS passes ago and never polled since: fold its reading into the slot that follows instead of losing it
+        // RANGE_SLOTS passes ago and never read since (the host ran that far ahead): wait for that pass and carry its count
+        // into the next report instead of losing it
         HIPCHK(h, hipEventSynchronize(sl.ev));
-        auto& next = h->range[(h->range_next + 1) % amx_handle_s::RANGE_SLOTS];
-        if (next.pending && !next.cont && *sl.host > 0) {
-            HIPCHK(h, hipEventSynchronize(next.ev));
-            *next.host += *sl.host;
-        }
+        h->range_carry += *sl.host;
         sl.pending = false;
     }
     HIPCHK(h, hipMemcpyAsync(sl.host, h->nonfinite, 4, hipMemcpyDeviceToHost, s));
