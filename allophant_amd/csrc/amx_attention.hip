@@ -47,7 +47,12 @@ constexpr float DEFER_THR = 8.0f;  // log2 units
 // workgroup per CU or less anyway (4 x 10 s: 256 workgroups of 128 queries), the serial key loop of a wave IS the launch; two
 // waves per SIMD halve it.  Every query's result is that of one wave with the same tiles in two groups: not bitwise the KS = 1
 // result (different rescale points), same gate.
-template <typename T, int NT, int WAVES, int KT, bool PACKED, int KS = 1>
+// TSTORE (round 5): the outputs leave through a per-wave LDS patch as whole lines.  A lane owns a query COLUMN of O^T and four-element
+// groups of its 64 values, so direct stores are 8 bytes per lane -- 16 instructions per wave, each touching 32 rows in 16-byte
+// pieces: 512 partial-line write requests for 8 KiB.  The patch (the idle K / V ring behind the last tile barrier; 32 rows x 256
+// bytes per wave, 16-byte chunks XOR-swizzled by the row) is read back row-major: 8 stores of 16 bytes per lane, whole 128-byte
+// lines.  Same values, same addresses: bitwise the direct form.
+template <typename T, int NT, int WAVES, int KT, bool PACKED, int KS = 1, bool TSTORE = true>
 __global__ __launch_bounds__(WAVES * KS * 64, AMX_ATTN_OCC) void attn_kernel(const AttnParams p) {
     constexpr int TILE = KT * 128;     // bytes of one K or V tile of one plane
     constexpr int NC = KT / 32;        // 32-key blocks per tile
@@ -359,6 +364,49 @@ __global__ __launch_bounds__(WAVES * KS * 64, AMX_ATTN_OCC) void attn_kernel(con
 #endif
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
+    if constexpr (TSTORE) {
+        const bool o_il = plane_is_il<NT>(p.out_plane);
+        if (NT == 1 || o_il) {  // (separate hi / lo planes -- non-wav2vec 2.0 widths -- keep the direct stores below)
+            constexpr int ROW = NT == 2 ? 256 : 128, CH = ROW / 16;  // bytes / 16-byte chunks of one query's head segment
+            unsigned char* patch = smem + (KS == 2 ? 40 * 1024 : 0) + wave * (32 * ROW);
+            const int sw = lq & (CH - 1);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    V4 hv, lv;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        T hi, lo = (T)0.f;
+                        split16<T, NT>(O[dt][4 * g + j] * inv, hi, lo);
+                        hv[j] = hi;
+                        lv[j] = lo;
+                    }
+                    // byte offset of the hi quad inside the segment: interleaved planes [hi x 32 | lo x 32] per 32 values
+                    const int o = NT == 2 ? dt * 128 + (8 * g + 4 * hh) * 2 : (dt * 32 + 8 * g + 4 * hh) * 2;
+                    *(V4*)(patch + lq * ROW + ((((o >> 4) ^ sw) << 4) | (o & 8))) = hv;
+                    if (NT > 1) *(V4*)(patch + lq * ROW + (((((o >> 4) + 4) ^ sw) << 4) | (o & 8))) = lv;
+                }
+            // (LDS operations of one wave complete in order: the reads below see the writes above)
+            const int limit = packed ? klen : p.T;
+            const int64_t row0 = packed ? (int64_t)roff : (int64_t)n * p.T;
+#pragma unroll
+            for (int q = 0; q < 32 * CH / 64; ++q) {
+                const int id = q * 64 + lane, row = id / CH, c = id % CH;
+                const uint4 v = *(const uint4*)(patch + row * ROW + ((c ^ (row & (CH - 1))) << 4));
+                const int qr = q_base + row;
+                if (qr < limit) {
+                    T* dst = (T*)p.out + pidx((row0 + qr) * (p.H * DH) + h * DH, o_il);
+                    *(uint4*)((unsigned char*)dst + c * 16) = v;
+                }
+            }
+#ifdef AMX_ATTN_STAMP
+            goto attn_stamp_out;
+#else
+            return;
+#endif
+        }
+    }
     if (query < (packed ? klen : p.T)) {
         // (the output feeds the out-projection GEMM: interleaved planes in the two-plane modes, amx_common.h pidx())
         const bool o_il = plane_is_il<NT>(p.out_plane);
@@ -381,6 +429,7 @@ __global__ __launch_bounds__(WAVES * KS * 64, AMX_ATTN_OCC) void attn_kernel(con
             }
     }
 #ifdef AMX_ATTN_STAMP
+attn_stamp_out:
     if (p.stamps && lane == 0) {
         const unsigned long long st_end = stamp();
         unsigned long long st_rt1;
@@ -747,11 +796,20 @@ void launch_attn_layout(const AttnParams& p, hipStream_t stream) {
 #else
     constexpr int lds = KS * 2 * NT * 2 * KT * 128;  // (KS == 2: at least the 4 x 8.5 KiB of the merge patches)
 #endif
+    const int qblocks = (p.T + WAVES * 32 - 1) / (WAVES * 32);
+    dim3 grid((unsigned)(8 * ((p.N * p.H + 7) / 8) * qblocks));
+    static const bool narrow = dev_switch("AMX_ATTN_NARROW_STORES");  // developer A/B switch: 8-byte stores straight from the registers
+    if (narrow) {
+        static OncePerDevice attr_n;
+        if (attr_n.first())
+            (void)hipFuncSetAttribute((const void*)attn_kernel<T, NT, WAVES, KT, PACKED, KS, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      lds);
+        hipLaunchKernelGGL((attn_kernel<T, NT, WAVES, KT, PACKED, KS, false>), grid, dim3(WAVES * KS * 64), lds, stream, p);
+        return;
+    }
     static OncePerDevice attr;
     if (attr.first())
         (void)hipFuncSetAttribute((const void*)attn_kernel<T, NT, WAVES, KT, PACKED, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    const int qblocks = (p.T + WAVES * 32 - 1) / (WAVES * 32);
-    dim3 grid((unsigned)(8 * ((p.N * p.H + 7) / 8) * qblocks));
     hipLaunchKernelGGL((attn_kernel<T, NT, WAVES, KT, PACKED, KS>), grid, dim3(WAVES * KS * 64), lds, stream, p);
 }
 
