@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of a measured and NOT adopted experiment: the kernel variant / developer switch it drives was removed again; the result is under profiles/r05_*)
 # round 5: attention Q rows coalesced through an LDS patch -- tests, then same-box A/B against the previous commit's library
 mkdir -p gpurun_out
 O=gpurun_out

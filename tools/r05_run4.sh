@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of a measured and NOT adopted experiment: the kernel variant / developer switch it drives was removed again; the result is under profiles/r05_*)
 # round 5, fourth box: LayerNorm rows with whole-line stores (DPP pair exchange) -- parity tests and same-box A/B
 mkdir -p gpurun_out
 O=gpurun_out

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of a measured and NOT adopted experiment: the kernel variant / developer switch it drives was removed again; the result is under profiles/r05_*)
 # round 5: attention -- static wave priority against the convoy of co-resident waves (developer build, AMX_ATTN_PRIO)
 mkdir -p gpurun_out
 O=gpurun_out/r05_attn_prio.log

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of a measured and NOT adopted experiment: the kernel variant / developer switch it drives was removed again; the result is under profiles/r05_*)
 # round 5: attention at 60 s utterances (attn2_kernel) -- static wave priority against the convoy of the two co-resident workgroups;
 # plus the range / graph tests on the tree with the carried range count
 mkdir -p gpurun_out
