@@ -729,23 +729,46 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 1 : 2) void attn2_kernel(c
             const int query = q_base + 32 * sb + lq;
             const float l_tot = l_run[sb] + __shfl_xor(l_run[sb], 32);
             const float inv = 1.0f / l_tot;
+            // Round 5: 16-byte stores.  A lane owns a query column of O^T and the 4-element groups 8g + 4hh + {0..3} of its 64 values
+            // (hh = which half of the wave), so the natural stores are 8 bytes per lane, 16 contiguous bytes per row and
+            // instruction.  v_permlane32_swap exchanges, per pair of groups (g, g + 1), the upper half's group g with the lower
+            // half's group g + 1: afterwards the lower lanes hold values 8g .. 8g + 7 and the upper lanes 8g + 8 .. 8g + 15 of their
+            // row -- one 16-byte store per pair, 32 contiguous bytes per row and instruction, half the write requests, no LDS
+            // round trip (cdna_hip_programming.md T21).  Same values to the same addresses.  Both halves of a query's lane pair
+            // take the branch together (same query).
             if (query < (PACKED ? klen : p.T)) {
                 T* dst = (T*)p.out + pidx(((PACKED ? (int64_t)cur.roff : (int64_t)cur.n * p.T) + query) * (p.H * DH) + cur.h * DH, o_il);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        V4 hv, lv;
+                    for (int g = 0; g < 4; g += 2) {
+                        uint2 h2[2], l2[2];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            T hi, lo = (T)0.f;
-                            split16<T, NT>(O[sb][dt][4 * g + j] * inv, hi, lo);
-                            hv[j] = hi;
-                            lv[j] = lo;
+                        for (int e = 0; e < 2; ++e) {
+                            V4 hv, lv;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                T hi, lo = (T)0.f;
+                                split16<T, NT>(O[sb][dt][4 * (g + e) + j] * inv, hi, lo);
+                                hv[j] = hi;
+                                lv[j] = lo;
+                            }
+                            h2[e] = __builtin_bit_cast(uint2, hv);
+                            l2[e] = __builtin_bit_cast(uint2, lv);
                         }
-                        const int d0 = (dt * 32 << (o_il ? 1 : 0)) + 8 * g + 4 * hh;
-                        *(V4*)(dst + d0) = hv;
-                        if (NT > 1) *(V4*)(dst + p.out_plane + d0) = lv;
+                        auto swap2 = [](uint2& a, uint2& b2) {  // vdst = group g, src = group g + 1
+                            auto rx = __builtin_amdgcn_permlane32_swap(a.x, b2.x, false, false);
+                            auto ry = __builtin_amdgcn_permlane32_swap(a.y, b2.y, false, false);
+                            a.x = rx[0]; b2.x = rx[1];
+                            a.y = ry[0]; b2.y = ry[1];
+                        };
+                        swap2(h2[0], h2[1]);
+                        const int d0 = (dt * 32 << (o_il ? 1 : 0)) + 8 * g + 8 * hh;
+                        *(uint4*)(dst + d0) = make_uint4(h2[0].x, h2[0].y, h2[1].x, h2[1].y);
+                        if (NT > 1) {
+                            swap2(l2[0], l2[1]);
+                            *(uint4*)(dst + p.out_plane + d0) = make_uint4(l2[0].x, l2[0].y, l2[1].x, l2[1].y);
+                        }
                     }
             }
         }
