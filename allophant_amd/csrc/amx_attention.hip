@@ -33,6 +33,57 @@ namespace {
 constexpr int DH = 64;
 constexpr float DEFER_THR = 8.0f;  // log2 units
 
+// The value of the lane 32 away, combined with this lane's, in the vector ALU: v_permlane32_swap of a register with a copy of
+// itself leaves the lower half's values in one register and the upper half's in the other, on every lane.  __shfl_xor(x, 32)
+// is a ds_bpermute, an LDS round trip (> 100 cycles) in the middle of the softmax's dependent chain.  max and + commute: the
+// same bits as the shuffle form.
+__device__ __forceinline__ void both_halves(float x, float& lower, float& upper) {
+    const unsigned b = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+    const unsigned r0 = r[0], r1 = r[1];  // (scalars first: __builtin_bit_cast of the ELEMENT r[1] reads element 0 with this clang)
+    lower = __builtin_bit_cast(float, r0);
+    upper = __builtin_bit_cast(float, r1);
+}
+// max as single instructions: fmaxf puts a canonicalising v_max_f32 x, x in front of every value the compiler cannot prove quiet
+// (MFMA outputs, lane swaps); v_max_f32 / v_max3_f32 return the other operand for a NaN either way
+__device__ __forceinline__ float maxn(float a, float b) {
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ float max3n(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float max_halves(float x) {
+    float lo, up;
+    both_halves(x, lo, up);
+    return maxn(lo, up);
+}
+__device__ __forceinline__ float sum_halves(float x) {
+    float lo, up;
+    both_halves(x, lo, up);
+    return lo + up;
+}
+// low plane of a split pair: lo = f16(x - hi).  x - float(hi) is exact in fp32 (hi is x rounded to 11 bits), so the fused form
+// fma(float(hi), -1, x) rounded once to f16 is the same value -- and one v_fma_mixlo / mixhi_f16 per value instead of a convert
+// back, a subtract and a share of a packed convert.  (bf16 has no mixed-precision fma: the three-step form.)
+template <typename T>
+__device__ __forceinline__ typename Vec2<T>::type residual2(f32x2 x, typename Vec2<T>::type hi) {
+    typedef typename Vec2<T>::type V2;
+    if constexpr (std::is_same<T, f16>::value) {
+        const unsigned h = __builtin_bit_cast(unsigned, hi);
+        unsigned lo;
+        asm("v_fma_mixlo_f16 %0, %1, %3, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(h), "v"(x[0]), "s"(-1.0f));
+        asm("v_fma_mixhi_f16 %0, %1, %3, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(h), "v"(x[1]), "s"(-1.0f));
+        return __builtin_bit_cast(V2, lo);
+    } else {
+        const f32x2 back = {(float)hi[0], (float)hi[1]};
+        return __builtin_convertvector(x - back, V2);
+    }
+}
+
 // waves per SIMD the register allocation must allow: two 8-wave workgroups or four 4-wave / 32-key workgroups per CU -> 4;
 // two 4-wave / 64-key workgroups -> 2
 #ifndef AMX_ATTN_OCC
@@ -648,14 +699,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 1 : 2) void attn2_kernel(c
 #pragma unroll
                         for (int r = 0; r < 16; ++r) X[sb][r] = (r & 3) + 8 * (r >> 2) < rem ? X[sb][r] : -INFINITY;
                     }
-                    float t0 = fmaxf(fmaxf(X[sb][0], X[sb][1]), X[sb][2]), t1 = fmaxf(fmaxf(X[sb][3], X[sb][4]), X[sb][5]);
+                    float t0 = max3n(X[sb][0], X[sb][1], X[sb][2]), t1 = max3n(X[sb][3], X[sb][4], X[sb][5]);
 #pragma unroll
                     for (int r = 6; r + 3 < 16; r += 4) {
-                        t0 = fmaxf(fmaxf(t0, X[sb][r]), X[sb][r + 1]);
-                        t1 = fmaxf(fmaxf(t1, X[sb][r + 2]), X[sb][r + 3]);
+                        t0 = max3n(t0, X[sb][r], X[sb][r + 1]);
+                        t1 = max3n(t1, X[sb][r + 2], X[sb][r + 3]);
                     }
-                    float mx = fmaxf(fmaxf(t0, t1), fmaxf(X[sb][14], X[sb][15]));
-                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    const float mx = max_halves(maxn(t0, max3n(t1, X[sb][14], X[sb][15])));
                     // the first block takes its own maximum; afterwards the maximum only moves when a block exceeds it by 2^THR
                     if (first_block || !__all(mx <= DEFER_THR)) {
                         const float d = first_block ? mx : fmaxf(mx, 0.f);
@@ -688,10 +738,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 1 : 2) void attn2_kernel(c
                             const f32x2 x = {X[sb][8 * s2 + 2 * j], X[sb][8 * s2 + 2 * j + 1]};
                             const V2 hi = __builtin_convertvector(x, V2);
                             ph[sb].h[j] = hi;
-                            if (NT > 1) {
-                                const f32x2 back = {(float)hi[0], (float)hi[1]};
-                                pl_[sb].h[j] = __builtin_convertvector(x - back, V2);
-                            }
+                            if (NT > 1) pl_[sb].h[j] = residual2<T>(x, hi);
                         }
                     const int koff = c * 4096 + s2 * 2048;  // key rows 32c + 16 s2 (+ 8g)
 #pragma unroll
@@ -727,7 +774,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 1 : 2) void attn2_kernel(c
 #pragma unroll
         for (int sb = 0; sb < SUB; ++sb) {
             const int query = q_base + 32 * sb + lq;
-            const float l_tot = l_run[sb] + __shfl_xor(l_run[sb], 32);
+            const float l_tot = sum_halves(l_run[sb]);
             const float inv = 1.0f / l_tot;
             // Round 5: 16-byte stores.  A lane owns a query column of O^T and the 4-element groups 8g + 4hh + {0..3} of its 64 values
             // (hh = which half of the wave), so the natural stores are 8 bytes per lane, 16 contiguous bytes per row and
