@@ -110,7 +110,6 @@ __global__ __launch_bounds__(WAVES * KS * 64, AMX_ATTN_OCC) void attn_kernel(con
     typedef typename Vec8<T>::type V8;
     typedef typename Vec4<T>::type V4;
     typedef short s16x4 __attribute__((__vector_size__(8)));
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef __attribute__((address_space(3))) s16x4* lds_s4_t;
     constexpr int QB = WAVES * 32;
     constexpr int STAGE = NT * 2 * TILE;  // [plane][K tile | V tile]
@@ -154,8 +153,7 @@ __global__ __launch_bounds__(WAVES * KS * 64, AMX_ATTN_OCC) void attn_kernel(con
     const int q_rows = packed ? p.Tp - roff : p.Tp;  // rows that may be read from `first` on
 
     const T* Qb = (const T*)p.q + first;
-    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.k + first), 0, -1, 0x00020000);
-    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.v + first), 0, -1, 0x00020000);
+    const dma_rsrc_t k_rsrc = dma_rsrc((const T*)p.k + first), v_rsrc = dma_rsrc((const T*)p.v + first);
     const uint32_t plane_b = (uint32_t)(p.qk_plane * 2);
 
     // Q fragments (B operand): lane (query, hh) holds Q[query][16ks + 8hh + j]
@@ -181,8 +179,8 @@ __global__ __launch_bounds__(WAVES * KS * 64, AMX_ATTN_OCC) void attn_kernel(con
                 const int piece = wave + WAVES * j;
                 const uint32_t so = (uint32_t)kt * TILE + pl * plane_b + piece * 1024;
                 unsigned char* dst = ring + st * STAGE + pl * 2 * TILE + piece * 1024;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_ptr_t)dst, 16, voff_k, so, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lds_ptr_t)(dst + TILE), 16, voff_v, so, 0, 0);
+                dma16(k_rsrc, dst, voff_k, so);  // (inline asm, not the builtin: amx_common.h)
+                dma16(v_rsrc, dst + TILE, voff_v, so);
             }
     };
 
@@ -208,6 +206,13 @@ __global__ __launch_bounds__(WAVES * KS * 64, AMX_ATTN_OCC) void attn_kernel(con
     if (my_tiles > 0) stage(kt0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    // the Q fragments have arrived (the wait above); a use the compiler can see, so that ITS wait for those loads sits here and not
+    // at their first use inside the key loop -- it does not see the DMA transfers (inline asm), so a "vmcnt(0) for the Q loads" in
+    // the loop would wait for every tile in flight, every iteration
+#pragma unroll
+    for (int pl = 0; pl < NT; ++pl)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(qf[pl][ks]));
 
 #ifdef AMX_ATTN_STAMP
     // developer diagnostic (tools/attn_bench.hip): cycles per phase of a key tile, summed in scalar registers
@@ -527,7 +532,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 1 : 2) void attn2_kernel(c
     typedef typename Vec4<T>::type V4;
     typedef typename Vec2<T>::type V2;
     typedef short s16x4 __attribute__((__vector_size__(8)));
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef __attribute__((address_space(3))) s16x4* lds_s4_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -570,8 +574,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 1 : 2) void attn2_kernel(c
         return it;
     };
     auto stage = [&](const Item& it, int kt) {
-        const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.k + it.first), 0, -1, 0x00020000);
-        const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.v + it.first), 0, -1, 0x00020000);
+        const dma_rsrc_t k_rsrc = dma_rsrc((const T*)p.k + it.first), v_rsrc = dma_rsrc((const T*)p.v + it.first);
 #pragma unroll
         for (int pl = 0; pl < NT; ++pl)
 #pragma unroll
@@ -579,8 +582,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 1 : 2) void attn2_kernel(c
                 const int piece = wave + WAVES * j;  // piece parity == wave parity: the swizzled source chunk is a per-lane constant
                 const uint32_t so = (uint32_t)kt * TILE + pl * plane_b + piece * 1024;
                 unsigned char* dst = smem + (kt & (STAGES - 1)) * STAGE + pl * 2 * TILE + piece * 1024;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_ptr_t)dst, 16, voff_k, so, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lds_ptr_t)(dst + TILE), 16, voff_v, so, 0, 0);
+                dma16(k_rsrc, dst, voff_k, so);  // (inline asm, not the builtin: amx_common.h)
+                dma16(v_rsrc, dst + TILE, voff_v, so);
             }
     };
     auto stage_head = [&](const Item& it) {
@@ -640,6 +643,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 1 : 2) void attn2_kernel(c
             for (int r = 0; r < 16; ++r) { O[sb][0][r] = 0.f; O[sb][1][r] = 0.f; }
         }
         bool first_block = true;
+        // a use of the Q fragments the compiler can see, in front of the key loop: its wait for those loads sits here (see attn_kernel)
+        // and not at their first use inside the loop, where "vmcnt(0)" would also wait for the tiles in flight, every iteration
+#pragma unroll
+        for (int sb = 0; sb < SUB; ++sb)
+#pragma unroll
+            for (int pl = 0; pl < NT; ++pl)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(qf[sb][pl][ks]));
 #ifdef AMX_ATTN_STAMP
         asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(a2_t1), "=s"(a2_c0)::"memory");
         a2_prev = a2_c0;

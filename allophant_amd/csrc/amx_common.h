@@ -45,6 +45,33 @@ inline int prec_planes(int p) { return p >= 2 ? 2 : 1; }
 // in LOGICAL elements; plane == PLANE_IL says that it is interleaved: logical element offset o (row * ld + column, ld % 32
 // == 0) then lives at pidx(o) and its lo value PLANE_IL elements behind -- "lo = hi + plane" holds in both layouts.
 constexpr int64_t PLANE_IL = 32;
+#ifdef __HIPCC__
+// LDS-DMA (buffer_load_dwordx4 ... lds: 16 bytes per lane, 1 KiB per wave instruction) written as inline asm.  With the builtin
+// (__builtin_amdgcn_raw_ptr_buffer_load_lds) the compiler tracks the transfer as a store to LDS at an address it cannot analyse and
+// puts s_waitcnt vmcnt(0) in front of the next LDS read with a memory operand -- i.e. in front of the first fragment read behind
+// every prefetch (which then waits for the tile just REQUESTED: the ring's run-ahead is gone) and in front of every LDS read of an
+// epilogue that alternates LDS reads and global stores (each store is waited for before the next read).  Kernels that read LDS
+// through plain C++ loads / ds_read builtins use this form; the hand-placed counted waits (s_waitcnt vmcnt(n) + barrier) are what
+// orders the transfers against the reads.  (Kernels whose LDS reads are inline asm too never had the problem.)
+typedef unsigned dma_rsrc_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ dma_rsrc_t dma_rsrc(const void* base) {  // raw buffer, no bounds (num_records = -1), like make_buffer_rsrc(base, 0, -1, 0x20000)
+    const uint64_t a = (uint64_t)base;
+    dma_rsrc_t r = {(unsigned)a, (unsigned)(a >> 32) & 0xffffu, 0xffffffffu, 0x00020000u};
+    return r;
+}
+__device__ __forceinline__ void dma16(dma_rsrc_t rsrc, const void* lds_dst, uint32_t voff, uint32_t soff) {
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const uint32_t lds_addr = (uint32_t)(uintptr_t)(lds_ptr_t)lds_dst;
+    // (m0 carries the LDS address of the transfer; naming it as clobbered draws -Winline-asm "reserved register": the compiler keeps
+    // nothing live in m0 across statements on gfx9 -- it loads m0 immediately in front of each use)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
+#pragma clang diagnostic pop
+}
+#endif
+
 __host__ __device__ __forceinline__ int64_t pidx(int64_t o, bool il) { return il ? (((o >> 5) << 6) | (o & 31)) : o; }
 template <int NT>
 __host__ __device__ __forceinline__ bool plane_is_il(int64_t plane) { return NT > 1 && plane == PLANE_IL; }

@@ -5,6 +5,7 @@
 #include "../allophant_amd/csrc/amx_attention.hip"
 #include "experiments/attn3_pingpong.inc"
 #include "experiments/attn4_subblock_pipeline.inc"
+#include "experiments/attn5_one_wave_per_simd.inc"
 #include <cstdio>
 #include <cmath>
 #include <cstdlib>
@@ -53,12 +54,17 @@ int main(int argc, char** argv) {
     std::vector<unsigned short> o1(out_elems), o2(out_elems);
     const int v2_waves = getenv("ATTN2_WAVES") ? atoi(getenv("ATTN2_WAVES")) : 8;
     const int base_waves = getenv("ATTN_BASE_WAVES") ? atoi(getenv("ATTN_BASE_WAVES")) : 8;  // 4: the short-batch form of attn_kernel
-    auto run1 = [&]() { if (base_waves == 4) launch_attn<f16, 2, 4, 64>(p, 0); else launch_attn<f16, 2, 8, 64>(p, 0); };
+    auto run1 = [&]() {
+        if (base_waves == 2) launch_attn2<f16, 2, 4, 2>(p, 256, 0);  // the library's long-utterance kernel as the baseline
+        else if (base_waves == 4) launch_attn<f16, 2, 4, 64>(p, 0);
+        else launch_attn<f16, 2, 8, 64>(p, 0);
+    };
     auto run2 = [&]() {
         if (v2_waves == 2) launch_attn<f16, 2, 4, 64, 2>(p, 0);  // attn_kernel with the key tiles split over two wave groups
         else if (v2_waves == 4) launch_attn2<f16, 2, 4, 2>(p, 256, 0);
         else if (v2_waves == 3) launch_attn4<f16, 2>(p, 256, 0);
         else if (v2_waves == 5) launch_attn3<f16, 2>(p, 256, 0);
+        else if (v2_waves == 6) launch_attn5<f16, 2>(p, 256, 0);
         else launch_attn2<f16, 2, 8, 4>(p, 256, 0);
     };
     CK(hipMemset(out, 0, out_elems * 2));
@@ -83,7 +89,8 @@ int main(int argc, char** argv) {
             worst = fmax(worst, fabs(v1 - v2));
             scale = fmax(scale, fabs(v1));
         }
-        printf("attn2 vs attn: max |difference| %.3e (largest output %.3f)\n", worst, scale);
+        printf("attn2 vs attn: max |difference| %.3e (largest output %.3f)%s\n", worst, scale,
+               memcmp(o1.data(), o2.data(), out_elems * 2) == 0 ? " -- BITWISE equal" : "");
     }
     for (int variant = 0; variant < 2; ++variant) {
         for (int i = 0; i < 3; ++i) { if (variant) run2(); else run1(); }
@@ -94,11 +101,28 @@ int main(int argc, char** argv) {
         CK(hipEventSynchronize(b));
         float ms;
         hipEventElapsedTime(&ms, a, b);
-        printf("%s f16x3 N=%d T=%d: %.1f us per launch, %.0f TFLOP/s algorithmic (x3 issued: %.0f)\n", variant ? (v2_waves == 2 ? "attn<4 waves, key split 2>" : v2_waves == 4 ? "attn2<4 waves, 2 slots>" : v2_waves == 5 ? "attn3 (ping-pong groups)" : v2_waves == 3 ? "attn4 (sub-blocks pipelined)" : "attn2<8 waves, 4 slots>") : (base_waves == 4 ? "attn<4 waves>" : "attn<8 waves>"), N, T,
+        printf("%s f16x3 N=%d T=%d: %.1f us per launch, %.0f TFLOP/s algorithmic (x3 issued: %.0f)\n", variant ? (v2_waves == 6 ? "attn5 (one wave per SIMD, sub-blocks pipelined)" : v2_waves == 2 ? "attn<4 waves, key split 2>" : v2_waves == 4 ? "attn2<4 waves, 2 slots>" : v2_waves == 5 ? "attn3 (ping-pong groups)" : v2_waves == 3 ? "attn4 (sub-blocks pipelined)" : "attn2<8 waves, 4 slots>") : (base_waves == 2 ? "attn2<4 waves, 2 slots>" : base_waves == 4 ? "attn<4 waves>" : "attn<8 waves>"), N, T,
                ms * 1e3 / reps, flop / (ms / reps) / 1e9, 3 * flop / (ms / reps) / 1e9);
     }
 #ifdef AMX_ATTN2_REPORT
-    if (v2_waves == 5) {
+    if (v2_waves == 6) {
+        const int items5 = 8 * ((N * H + 7) / 8) * ((T + 255) / 256);
+        CK(hipMemset(st, 0, (size_t)wgs * 8 * 12 * 8));
+        run2();
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> h5((size_t)items5 * 4 * 8);
+        CK(hipMemcpy(h5.data(), st, h5.size() * 8, hipMemcpyDeviceToHost));
+        double ph[6] = {0}, tiles = 0;
+        for (size_t w = 0; w < (size_t)items5 * 4; ++w) {
+            const unsigned long long* o = &h5[w * 8];
+            if (!o[7]) continue;
+            for (int i = 0; i < 6; ++i) ph[i] += (double)o[i];
+            tiles += (double)o[6];
+        }
+        printf("attn5 cycles per 64-key tile and wave (stamped build): wait + barrier %.0f | K reads + DMA issue %.0f | A %.0f | B %.0f | C %.0f | D %.0f | sum %.0f\n",
+               ph[0] / tiles, ph[1] / tiles, ph[2] / tiles, ph[3] / tiles, ph[4] / tiles, ph[5] / tiles,
+               (ph[0] + ph[1] + ph[2] + ph[3] + ph[4] + ph[5]) / tiles);
+    } else if (v2_waves == 5) {
         CK(hipMemset(st, 0, (size_t)wgs * 8 * 12 * 8));
         run2();
         CK(hipDeviceSynchronize());
