@@ -44,22 +44,13 @@ __device__ __forceinline__ void both_halves(float x, float& lower, float& upper)
     lower = __builtin_bit_cast(float, r0);
     upper = __builtin_bit_cast(float, r1);
 }
-// max as single instructions: fmaxf puts a canonicalising v_max_f32 x, x in front of every value the compiler cannot prove quiet
-// (MFMA outputs, lane swaps); v_max_f32 / v_max3_f32 return the other operand for a NaN either way
-__device__ __forceinline__ float maxn(float a, float b) {
-    float d;
-    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-__device__ __forceinline__ float max3n(float a, float b, float c) {
-    float d;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
+// (The max trees stay plain fmaxf.  Written as inline-asm v_max3_f32 they save the canonicalising v_max x, x the compiler puts in
+// front of MFMA outputs, but the compiler does not place the MFMA -> VALU-read wait states in front of an asm statement that reads
+// an accumulator: the scores of a block would be read on timing luck.)
 __device__ __forceinline__ float max_halves(float x) {
     float lo, up;
     both_halves(x, lo, up);
-    return maxn(lo, up);
+    return fmaxf(lo, up);
 }
 __device__ __forceinline__ float sum_halves(float x) {
     float lo, up;
@@ -710,13 +701,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 1 : 2) void attn2_kernel(c
 #pragma unroll
                         for (int r = 0; r < 16; ++r) X[sb][r] = (r & 3) + 8 * (r >> 2) < rem ? X[sb][r] : -INFINITY;
                     }
-                    float t0 = max3n(X[sb][0], X[sb][1], X[sb][2]), t1 = max3n(X[sb][3], X[sb][4], X[sb][5]);
+                    float t0 = fmaxf(fmaxf(X[sb][0], X[sb][1]), X[sb][2]), t1 = fmaxf(fmaxf(X[sb][3], X[sb][4]), X[sb][5]);
 #pragma unroll
                     for (int r = 6; r + 3 < 16; r += 4) {
-                        t0 = max3n(t0, X[sb][r], X[sb][r + 1]);
-                        t1 = max3n(t1, X[sb][r + 2], X[sb][r + 3]);
+                        t0 = fmaxf(fmaxf(t0, X[sb][r]), X[sb][r + 1]);
+                        t1 = fmaxf(fmaxf(t1, X[sb][r + 2]), X[sb][r + 3]);
                     }
-                    const float mx = max_halves(maxn(t0, max3n(t1, X[sb][14], X[sb][15])));
+                    const float mx = max_halves(fmaxf(fmaxf(t0, t1), fmaxf(X[sb][14], X[sb][15])));
                     // the first block takes its own maximum; afterwards the maximum only moves when a block exceeds it by 2^THR
                     if (first_block || !__all(mx <= DEFER_THR)) {
                         const float d = first_block ? mx : fmaxf(mx, 0.f);

@@ -4,6 +4,15 @@
 # 4 / 5 and of the wav2vec2-base family, and the geometry sweep of this tree against the round-4 library
 mkdir -p gpurun_out
 O=gpurun_out
+# output bits of this tree against the library of an earlier commit of the round (build/ab/head.so, tools/ab_build.sh): the late attention
+# changes (store shape, instruction selection, DMA form) claim "same values"
+if [ -f build/ab/head.so ]; then
+  for P in f16x3 bf16x3; do
+    AMX_LIB_PATH=$PWD/build/ab/head.so timeout 600 python tools/ab_bitwise.py $P 1:3 4:10 32:10 8:60 2>/dev/null > $O/bits_head_$P.txt
+    timeout 600 python tools/ab_bitwise.py $P 1:3 4:10 32:10 8:60 2>/dev/null > $O/bits_tree_$P.txt
+  done
+  (for P in f16x3 bf16x3; do if diff -q $O/bits_head_$P.txt $O/bits_tree_$P.txt > /dev/null; then echo "$P: this tree is bitwise the earlier library on every geometry ($(wc -l < $O/bits_tree_$P.txt) digests)"; else echo "$P: DIFFERS"; diff $O/bits_head_$P.txt $O/bits_tree_$P.txt; fi; done) > $O/r05_final_bitwise.log
+fi
 (timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | grep -v "version\|Hostname\|Librccl" | tail -8) > $O/r05_gpu_suite.log
 bash tools/profile_bench.sh r05_f16x3 --precision f16x3 > $O/r05_profile_f16x3.log 2>&1
 bash tools/profile_bench.sh r05_bf16 --precision bf16 > $O/r05_profile_bf16.log 2>&1
@@ -36,4 +45,4 @@ for name in ("r05_bench_line", "r05_bench_config4", "r05_bench_config5", "r05_be
     except Exception as e:
         print(name, "ERROR", e)
 PY
-cat $O/r05_gpu_suite.log $O/r05_collect.log $O/r05_race_screen.log; cut -c1-200 $O/r05_geometry_sweep_final.log; tail -3 $O/r05_bench_stderr.log
+cat $O/r05_final_bitwise.log $O/r05_gpu_suite.log $O/r05_collect.log $O/r05_race_screen.log; cut -c1-200 $O/r05_geometry_sweep_final.log; tail -3 $O/r05_bench_stderr.log
