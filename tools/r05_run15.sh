@@ -4,7 +4,7 @@
 mkdir -p gpurun_out
 O=gpurun_out/r05_attn5.log
 rm -f $O
-for g in ${GEOMS:-"8 2999" "16 999" "32 499"}; do
+for g in "8 2999" "16 999"; do
   echo "== N T = $g" >> $O
   ATTN_BASE_WAVES=2 ATTN2_WAVES=6 timeout 120 build/attn_bench $g 2>&1 | tail -3 >> $O
 done
