@@ -80,3 +80,42 @@ def test_key_loops_hold_no_scratch_traffic_and_the_dma_is_inline_asm(attention_i
                 raise AssertionError(f"{name}: spill traffic inside the key loop: {text}")
             if "offen lds" in text:
                 assert in_asm, f"{name}: LDS-DMA issued through the builtin, not dma16: {text}"
+
+
+@pytest.fixture(scope="module")
+def gemm_isa(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("isa_gemm") / "amx_gemm.s"
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{ROOT}/include", f"-I{ROOT}/allophant_amd/csrc",
+           "--cuda-device-only", "-S", "-o", str(out), f"{ROOT}/allophant_amd/csrc/amx_gemm.hip"]
+    subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1800)
+    return out.read_text().splitlines()
+
+
+def test_ping_pong_gemm_k_loop_has_only_hand_placed_waits_and_no_spills(gemm_isa):
+    """`gemm_pp_kernel` (70 % of the step): inside the K loop (depth 2 of the persistent tile loop) every `s_waitcnt vmcnt` is one
+    of the ring's counted waits (inline asm), nothing is spilled, and the loop holds MFMAs at all (the right blocks are looked at)."""
+    lines, checked, i = gemm_isa, 0, 0
+    while i < len(lines):
+        m = re.match(r"^(_ZN3amx\S*gemm_pp_kernel\S*):", lines[i])
+        if m:
+            end = next(j for j in range(i, len(lines)) if "s_endpgm" in lines[j])
+            in_asm, label, mfma_in_loop = False, "", 0
+            for line in lines[i:end]:
+                if line.startswith(".LBB"):
+                    label = line
+                if "#ASMSTART" in line:
+                    in_asm = True
+                if "#ASMEND" in line:
+                    in_asm = False
+                text = line.strip()
+                if "Depth=2" in label:
+                    mfma_in_loop += text.startswith("v_mfma")
+                    assert not ("vmcnt" in text and not in_asm), f"{m.group(1)}: compiler-inserted wait in the K loop: {text}"
+                    assert not text.startswith("scratch_"), f"{m.group(1)}: spill traffic in the K loop: {text}"
+            assert mfma_in_loop >= 48, f"{m.group(1)}: K loop not found ({mfma_in_loop} MFMAs at depth 2)"
+            checked += 1
+            i = end
+        i += 1
+    assert checked >= 8, f"only {checked} gemm_pp_kernel instances found"
