@@ -6,6 +6,7 @@
 #include "experiments/attn3_pingpong.inc"
 #include "experiments/attn4_subblock_pipeline.inc"
 #include "experiments/attn5_one_wave_per_simd.inc"
+#include "experiments/attn6_straddled_softmax.inc"
 #include <cstdio>
 #include <cmath>
 #include <cstdlib>
@@ -65,6 +66,7 @@ int main(int argc, char** argv) {
         else if (v2_waves == 3) launch_attn4<f16, 2>(p, 256, 0);
         else if (v2_waves == 5) launch_attn3<f16, 2>(p, 256, 0);
         else if (v2_waves == 6) launch_attn5<f16, 2>(p, 256, 0);
+        else if (v2_waves == 7) launch_attn6<f16, 2>(p, 256, 0);
         else launch_attn2<f16, 2, 8, 4>(p, 256, 0);
     };
     CK(hipMemset(out, 0, out_elems * 2));
@@ -101,11 +103,11 @@ int main(int argc, char** argv) {
         CK(hipEventSynchronize(b));
         float ms;
         hipEventElapsedTime(&ms, a, b);
-        printf("%s f16x3 N=%d T=%d: %.1f us per launch, %.0f TFLOP/s algorithmic (x3 issued: %.0f)\n", variant ? (v2_waves == 6 ? "attn5 (one wave per SIMD, sub-blocks pipelined)" : v2_waves == 2 ? "attn<4 waves, key split 2>" : v2_waves == 4 ? "attn2<4 waves, 2 slots>" : v2_waves == 5 ? "attn3 (ping-pong groups)" : v2_waves == 3 ? "attn4 (sub-blocks pipelined)" : "attn2<8 waves, 4 slots>") : (base_waves == 2 ? "attn2<4 waves, 2 slots>" : base_waves == 4 ? "attn<4 waves>" : "attn<8 waves>"), N, T,
+        printf("%s f16x3 N=%d T=%d: %.1f us per launch, %.0f TFLOP/s algorithmic (x3 issued: %.0f)\n", variant ? (v2_waves == 7 ? "attn6 (one wave per SIMD, softmax straddling two MFMA groups)" : v2_waves == 6 ? "attn5 (one wave per SIMD, sub-blocks pipelined)" : v2_waves == 2 ? "attn<4 waves, key split 2>" : v2_waves == 4 ? "attn2<4 waves, 2 slots>" : v2_waves == 5 ? "attn3 (ping-pong groups)" : v2_waves == 3 ? "attn4 (sub-blocks pipelined)" : "attn2<8 waves, 4 slots>") : (base_waves == 2 ? "attn2<4 waves, 2 slots>" : base_waves == 4 ? "attn<4 waves>" : "attn<8 waves>"), N, T,
                ms * 1e3 / reps, flop / (ms / reps) / 1e9, 3 * flop / (ms / reps) / 1e9);
     }
 #ifdef AMX_ATTN2_REPORT
-    if (v2_waves == 6) {
+    if (v2_waves == 6 || v2_waves == 7) {
         const int items5 = 8 * ((N * H + 7) / 8) * ((T + 255) / 256);
         CK(hipMemset(st, 0, (size_t)wgs * 8 * 12 * 8));
         run2();
@@ -119,6 +121,10 @@ int main(int argc, char** argv) {
             for (int i = 0; i < 6; ++i) ph[i] += (double)o[i];
             tiles += (double)o[6];
         }
+        if (v2_waves == 7)
+            printf("attn6 cycles per 64-key tile and wave (stamped build): part I head %.0f | part I body %.0f | K reads / hand-off %.0f | part II head %.0f | part II body %.0f | sum %.0f\n",
+                   ph[0] / tiles, ph[1] / tiles, ph[2] / tiles, ph[3] / tiles, ph[4] / tiles, (ph[0] + ph[1] + ph[2] + ph[3] + ph[4]) / tiles);
+        else
         printf("attn5 cycles per 64-key tile and wave (stamped build): wait + barrier %.0f | K reads + DMA issue %.0f | A %.0f | B %.0f | C %.0f | D %.0f | sum %.0f\n",
                ph[0] / tiles, ph[1] / tiles, ph[2] / tiles, ph[3] / tiles, ph[4] / tiles, ph[5] / tiles,
                (ph[0] + ph[1] + ph[2] + ph[3] + ph[4] + ph[5]) / tiles);

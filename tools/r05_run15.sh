@@ -6,7 +6,7 @@ O=gpurun_out/r05_attn5.log
 rm -f $O
 for g in "8 2999" "16 999"; do
   echo "== N T = $g" >> $O
-  ATTN_BASE_WAVES=2 ATTN2_WAVES=6 timeout 120 build/attn_bench $g 2>&1 | tail -3 >> $O
+  ATTN_BASE_WAVES=2 ATTN2_WAVES=${A5V:-6} timeout 120 build/attn_bench $g 2>&1 | tail -3 >> $O
 done
-ATTN_BASE_WAVES=2 ATTN2_WAVES=6 timeout 120 build/attn_bench_stamp 8 2999 2>&1 | grep "attn5 cycles" >> $O
+ATTN_BASE_WAVES=2 ATTN2_WAVES=${A5V:-6} timeout 120 build/attn_bench_stamp 8 2999 2>&1 | grep "cycles per 64-key" >> $O
 cat $O
