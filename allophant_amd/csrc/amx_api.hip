@@ -24,6 +24,9 @@ struct Layer {
     void *wqkv, *wo, *w1, *w2;
     float *bqkv, *bo, *b1, *b2;
     float r_qkv = 1.f, r_o = 1.f, r_1 = 1.f, r_2 = 1.f;  // 1 / (power of two the packed planes were multiplied by)
+    // pre-LN layers: the LayerNorm in front of QKV / FFN1 is folded into those products (GemmParams.row_coef): wqkv / w1 hold
+    // gamma (.) W, bqkv / b1 hold d = W beta + b, and c = W gamma (row sums of the folded weights) is what the mean term multiplies
+    float *c_qkv = nullptr, *c_1 = nullptr;
 };
 
 // One GEMM (or GEMM pair for the composition head) of the hierarchical projection
@@ -92,6 +95,7 @@ struct amx_handle_s {
     float* pos_b = nullptr;
     std::vector<Layer> layers;
     float *fln_g = nullptr, *fln_b = nullptr;
+    float *unit_g = nullptr, *zero_b = nullptr;  // [hidden] ones / zeros
     std::vector<HeadStep> steps;
     float* emb = nullptr;  // composition embedding table [rows, E]
     int emb_rows = 0;
@@ -189,6 +193,7 @@ struct amx_handle_s {
     int64_t range_carry = 0;  // count of a slot that had to be reused before any call had read it
     // last forward geometry
     int last_N = 0;
+    bool last_fold = false;  // the last pass ran its encoder layers with the LayerNorm fold (reported by amx_graph_info's sibling below)
     bool qkv_dirty = false;
     int64_t last_L = 0, last_T = 0;
     bool last_keep = false;
@@ -353,6 +358,35 @@ static int pack_linear(amx_handle h, const TensorMap& tm, const std::string& key
                        cols_pad, 0);
     HIPCHK(h, hipDeviceSynchronize());
     return AMX_OK;
+}
+
+// the same from host data (weights amx_create folds before packing)
+static int pack_linear_host(amx_handle h, const float* data, int rows, int cols, float scale, void* dst, int64_t plane, int64_t ldd,
+                            int row0, int cols_pad, float* staging) {
+    HIPCHK(h, hipMemcpy(staging, data, (size_t)rows * cols * 4, hipMemcpyHostToDevice));
+    launch_pack_matrix(h->prec, staging, rows, cols, cols, 1, scale, (char*)dst + (size_t)row0 * ldd * 2 * (plane == PLANE_IL ? 2 : 1), plane, ldd,
+                       cols_pad, 0);
+    HIPCHK(h, hipDeviceSynchronize());
+    return AMX_OK;
+}
+
+// LayerNorm(gamma, beta) folded into the Linear(W [rows, cols], b) behind it:  LN(x) W^T + b = rstd ((x - p) . (gamma (.) W)^T)
+// - rstd (mu - p) c + d  with  c = W gamma,  d = W beta + b  (fp64 sums; `pre` multiplies everything: the attention's query scale).
+// folded: gamma (.) W * pre in fp32 (one rounding at 2^-24, below the 2^-22 of the planes); c from those values, as the product sees them
+static void fold_layer_norm(const float* W, const float* b, const float* gamma, const float* beta, int rows, int cols, float pre,
+                            float* folded, float* c, float* d) {
+    for (int r = 0; r < rows; ++r) {
+        double cs = 0.0, ds = 0.0;
+        const float* w = W + (size_t)r * cols;
+        float* f = folded + (size_t)r * cols;
+        for (int k = 0; k < cols; ++k) {
+            f[k] = w[k] * gamma[k] * pre;
+            cs += (double)f[k];
+            ds += (double)w[k] * (double)beta[k];
+        }
+        c[r] = (float)cs;
+        d[r] = (float)((ds + (double)b[r]) * (double)pre);
+    }
 }
 
 // power of two that puts the largest |w * pre| of the listed tensors into [4096, 8192); 1 for empty / zero / non-finite data
@@ -622,6 +656,47 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
         ly.bqkv = (float*)dev_alloc(h, (size_t)3 * D * 4);
         if (!ly.wqkv || !ly.wo || !ly.w1 || !ly.w2 || !ly.bqkv) { h->err = "device allocation failed"; return bail(AMX_ENOMEM); }
         const char* names[3] = {"q_proj", "k_proj", "v_proj"};
+        if (h->stable) {
+            // pre-LN layer: `layer_norm` folded into Q / K / V, `final_layer_norm` into FFN1 (see fold_layer_norm)
+            const amx_tensor *g1 = tm.get(p + "layer_norm.weight"), *be1 = tm.get(p + "layer_norm.bias");
+            const amx_tensor *g2 = tm.get(p + "final_layer_norm.weight"), *be2 = tm.get(p + "final_layer_norm.bias");
+            std::vector<float> folded((size_t)std::max(3 * D, F) * D), cvec(std::max(3 * D, F)), dvec(std::max(3 * D, F));
+            for (int j = 0; j < 3; ++j) {
+                const amx_tensor* w = tm.get(p + "attention." + names[j] + ".weight");
+                const amx_tensor* b = tm.get(p + "attention." + names[j] + ".bias");
+                if (!w || w->numel != (int64_t)D * D || !b || b->numel != D) { h->err = "missing or mis-shaped tensor " + p + "attention." + names[j]; return bail(AMX_EINVAL); }
+                fold_layer_norm(w->data, b->data, g1->data, be1->data, D, D, j == 0 ? qscale : 1.f, folded.data() + (size_t)j * D * D,
+                                cvec.data() + j * D, dvec.data() + j * D);
+            }
+            amx_tensor ft{};
+            ft.data = folded.data(); ft.numel = (int64_t)3 * D * D;
+            const float ps_qkv = pack_scale({{&ft, 1.f}});
+            ly.r_qkv = 1.f / ps_qkv;
+            TRY(pack_linear_host(h, folded.data(), 3 * D, D, ps_qkv, ly.wqkv, pln(h, (int64_t)3 * D * D), D, 0, D, staging));
+            ly.c_qkv = (float*)dev_alloc(h, (size_t)3 * D * 4);
+            if (!ly.c_qkv || hipMemcpy(ly.c_qkv, cvec.data(), (size_t)3 * D * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(ly.bqkv, dvec.data(), (size_t)3 * D * 4, hipMemcpyHostToDevice) != hipSuccess) { h->err = "device allocation failed"; return bail(AMX_ENOMEM); }
+            const amx_tensor* w1 = tm.get(p + "feed_forward.intermediate_dense.weight");
+            const amx_tensor* b1 = tm.get(p + "feed_forward.intermediate_dense.bias");
+            if (!w1 || w1->numel != (int64_t)F * D || !b1 || b1->numel != F) { h->err = "missing or mis-shaped tensor " + p + "feed_forward.intermediate_dense"; return bail(AMX_EINVAL); }
+            fold_layer_norm(w1->data, b1->data, g2->data, be2->data, F, D, 1.f, folded.data(), cvec.data(), dvec.data());
+            ft.numel = (int64_t)F * D;
+            const float ps_1 = pack_scale({{&ft, 1.f}});
+            ly.r_1 = 1.f / ps_1;
+            TRY(pack_linear_host(h, folded.data(), F, D, ps_1, ly.w1, pln(h, (int64_t)F * D), D, 0, D, staging));
+            ly.c_1 = (float*)dev_alloc(h, (size_t)F * 4);
+            ly.b1 = (float*)dev_alloc(h, (size_t)F * 4);
+            if (!ly.c_1 || !ly.b1 || hipMemcpy(ly.c_1, cvec.data(), (size_t)F * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(ly.b1, dvec.data(), (size_t)F * 4, hipMemcpyHostToDevice) != hipSuccess) { h->err = "device allocation failed"; return bail(AMX_ENOMEM); }
+            const float ps_o = pack_scale({{tm.get(p + "attention.out_proj.weight"), 1.f}});
+            const float ps_2 = pack_scale({{tm.get(p + "feed_forward.output_dense.weight"), 1.f}});
+            ly.r_o = 1.f / ps_o; ly.r_2 = 1.f / ps_2;
+            TRY(pack_linear(h, tm, p + "attention.out_proj.weight", D, D, ps_o, ly.wo, pln(h, (int64_t)D * D), D, 0, D, staging));
+            TRY(upload_f32(h, tm, p + "attention.out_proj.bias", D, &ly.bo));
+            TRY(pack_linear(h, tm, p + "feed_forward.output_dense.weight", D, F, ps_2, ly.w2, pln(h, (int64_t)D * F), F, 0, F, staging));
+            TRY(upload_f32(h, tm, p + "feed_forward.output_dense.bias", D, &ly.b2));
+            continue;
+        }
         const float ps_qkv = pack_scale({{tm.get(p + "attention.q_proj.weight"), qscale}, {tm.get(p + "attention.k_proj.weight"), 1.f},
                                          {tm.get(p + "attention.v_proj.weight"), 1.f}});
         ly.r_qkv = 1.f / ps_qkv;
@@ -644,6 +719,13 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
         TRY(upload_f32(h, tm, p + "feed_forward.intermediate_dense.bias", F, &ly.b1));
         TRY(pack_linear(h, tm, p + "feed_forward.output_dense.weight", D, F, ps_2, ly.w2, pln(h, (int64_t)D * F), F, 0, F, staging));
         TRY(upload_f32(h, tm, p + "feed_forward.output_dense.bias", D, &ly.b2));
+    }
+    {   // the affine part of a folded LayerNorm lives in the weights: its row pass (short batches) normalises with (1, 0)
+        std::vector<float> ones(D, 1.f);
+        h->unit_g = (float*)dev_alloc(h, (size_t)D * 4);
+        h->zero_b = (float*)dev_alloc(h, (size_t)D * 4);
+        if (!h->unit_g || !h->zero_b || hipMemcpy(h->unit_g, ones.data(), (size_t)D * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemset(h->zero_b, 0, (size_t)D * 4) != hipSuccess) { h->err = "device allocation failed"; return bail(AMX_ENOMEM); }
     }
     TRY(upload_f32(h, tm, AM + "encoder.layer_norm.weight", D, &h->fln_g));
     TRY(upload_f32(h, tm, AM + "encoder.layer_norm.bias", D, &h->fln_b));
@@ -1433,12 +1515,89 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         }
     }
     const bool needs_qkv_zero = !packed && (h->last_N != N || h->last_T != T || h->qkv_dirty);
+    // ---- the encoder layers' products (plan: the enqueue region only launches them) ----
+    const int64_t Mrows = packed ? Mp : M;  // rows the layers work on
+    const int64_t xp_plane = pln(h, Mrows * D);
+    const int64_t qk_plane = packed ? (int64_t)H * TpTot * 64 : (int64_t)N * H * Tp * 64;
+    float* const stream = (float*)(packed ? hpk : hbuf);  // the residual stream of the layers [Mrows, D]
+    auto with_ws = [&](GemmParams g) {
+        g.splitk_ws = (float*)splitk;
+        g.splitk_ws_elems = splitk ? (int64_t)(SPLITK_BYTES / 4) : 0;
+        return g;
+    };
+    auto qkv_params = [&](const Layer& ly) {
+        GemmParams g{};
+        g.A = xp; g.a_plane = xp_plane; g.lda = D; g.rows_per_batch = Mrows;
+        g.W = ly.wqkv; g.w_plane = pln(h, (int64_t)3 * D * D); g.ldw = D;
+        g.M = (int)Mrows; g.N = 3 * D; g.K = D;
+        g.scale = ly.r_qkv; g.bias = ly.bqkv;
+        g.mode = 1; g.q = qb; g.k = kb; g.v = vtb;
+        g.qk_plane = qk_plane;
+        // packed rows: one "utterance" of Mp rows, so the scatter writes row m of head hh to [hh][m][:]
+        g.T = packed ? (int)std::max<int64_t>(Mp, 8) : T; g.Tp = packed ? TpTot : Tp; g.H = H; g.dh = 64;
+        return with_ws(g);
+    };
+    auto oproj_params = [&](const Layer& ly) {
+        GemmParams g{};
+        g.A = ao; g.a_plane = xp_plane; g.lda = D; g.rows_per_batch = Mrows;
+        g.W = ly.wo; g.w_plane = pln(h, (int64_t)D * D); g.ldw = D;
+        g.M = (int)Mrows; g.N = D; g.K = D;
+        g.scale = ly.r_o; g.bias = ly.bo;
+        g.residual = stream; g.ldr = D; g.out_f32 = stream; g.ldo = D;
+        return with_ws(g);
+    };
+    auto ffn1_params = [&](const Layer& ly) {
+        GemmParams g{};
+        g.A = xp; g.a_plane = xp_plane; g.lda = D; g.rows_per_batch = Mrows;
+        g.W = ly.w1; g.w_plane = pln(h, (int64_t)F * D); g.ldw = D;
+        g.M = (int)Mrows; g.N = F; g.K = D;
+        g.scale = ly.r_1; g.bias = ly.b1; g.act = 1;
+        g.out_p = ff; g.out_plane = pln(h, Mrows * F); g.ldp = F;
+        return with_ws(g);
+    };
+    auto ffn2_params = [&](const Layer& ly) {
+        GemmParams g{};
+        g.A = ff; g.a_plane = pln(h, Mrows * F); g.lda = F; g.rows_per_batch = Mrows;
+        g.W = ly.w2; g.w_plane = pln(h, (int64_t)D * F); g.ldw = F;
+        g.M = (int)Mrows; g.N = D; g.K = F;
+        g.scale = ly.r_2; g.bias = ly.b2;
+        g.residual = stream; g.ldr = D; g.out_f32 = stream; g.ldo = D;
+        return with_ws(g);
+    };
+    // LayerNorm fold (pre-LN layers; GemmParams.ln_partial / row_coef): the out-projection and FFN2 leave the planes and the row
+    // statistics of the stream they have just updated, QKV and FFN1 apply the normalisation in their epilogues -- no LayerNorm
+    // pass between the products of a layer.  Only where all four products run on the ping-pong kernel in one piece (batches
+    // from a few thousand frames: every benchmark configuration); short batches keep the row pass -- with (1, 0) as its affine
+    // part, since the weights hold gamma and beta either way -- fused with the split-K fix-up as before.
+    static const bool no_ln_fold = dev_switch("AMX_NO_LN_FOLD");  // developer A/B switch
+    void *ln_rowps = nullptr, *ln_coef = nullptr, *ln_partial = nullptr;
+    bool fold = false;
+    auto as_consumer = [&](GemmParams g, const float* col_c) {
+        g.row_coef = (const float2*)ln_coef; g.col_c = col_c;
+        return g;
+    };
+    auto as_producer = [&](GemmParams g) {
+        g.ln_partial = (float2*)ln_partial; g.ln_rowps = (const float2*)ln_rowps;
+        g.out_p = xp; g.out_plane = xp_plane; g.ldp = D;
+        return g;
+    };
+    if (stable && !no_ln_fold && c.layers > 0 && D % 64 == 0 && D <= 1024) {
+        WS("ln_rowps", (size_t)Mrows * 8, ln_rowps);
+        WS("ln_coef", (size_t)Mrows * 8, ln_coef);
+        WS("ln_partial", (size_t)Mrows * (D / 64) * 8, ln_partial);
+        const Layer& ly = h->layers[0];
+        fold = gemm_ln_fold_ok(prec, as_consumer(qkv_params(ly), ly.c_qkv)) && gemm_ln_fold_ok(prec, as_producer(oproj_params(ly))) &&
+               gemm_ln_fold_ok(prec, as_consumer(ffn1_params(ly), ly.c_1)) && gemm_ln_fold_ok(prec, as_producer(ffn2_params(ly)));
+    }
+    h->last_fold = fold;
+    void* const hbuf_plan = hbuf;
 
     // =============================================================================================================
     // enqueue: the whole pass on stream `s` -- memsets, kernels, device-to-device copies only (eagerly on the caller's
     // stream, or once on the capture stream when the pass is recorded into a HIP graph)
     // =============================================================================================================
     auto enqueue = [&](hipStream_t s) -> int {
+    void* hbuf = hbuf_plan;  // (local: the region may run twice -- once into a recording that fails, then eagerly)
     // K/V/Q padding rows [T, Tp) must stay finite: re-zero when the geometry changes
     // (zero fills inside a pass are kernels, never memsets: amx_rowops.hip, launch_zero)
     if (needs_qkv_zero) {
@@ -1594,22 +1753,16 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     }
     // ---- transformer encoder (pre-LN) ----
     void* const hpad = hbuf;     // the padded residual stream [N * T, D]
-    const int64_t Mpad = M;
     if (packed) {
         if (!packed_early) { Timed t_(h, AMX_KC_OTHER); launch_pack_rows((const float*)hpad, (float*)hpk, (const int*)d_rowoff, (const int*)d_frames, N, T, D, false, s); }
         hbuf = hpk;
     }
-    const int64_t Mrows = packed ? Mp : Mpad;  // rows the layers work on
-    const int64_t xp_plane = pln(h, Mrows * D);
-    const int64_t qk_plane = packed ? (int64_t)H * TpTot * 64 : (int64_t)N * H * Tp * 64;
     // A residual product that launch_gemm cuts into K chunks (short batches) leaves its fix-up -- slab sum + bias + residual
     // -> h -- to the LayerNorm that follows it: one kernel instead of the fix-up and a LayerNorm pass that re-reads h
     // (AMX_NO_FUSED_FIXUP=1: developer A/B switch).
     static const bool no_fused_fixup = dev_switch("AMX_NO_FUSED_FIXUP");
     struct { bool on = false; GemmParams g; int splits = 0; } pending;
-    auto residual_gemm = [&](GemmParams& g, bool may_defer) {
-        g.splitk_ws = (float*)splitk;
-        g.splitk_ws_elems = splitk ? (int64_t)(SPLITK_BYTES / 4) : 0;
+    auto residual_gemm = [&](GemmParams g, bool may_defer) {
         const int splits = may_defer && !no_fused_fixup ? gemm_planned_splits(prec, g) : 1;
         if (splits > 1 && fixup_rownorm_eligible(g)) {
             g.defer_fixup = 1;
@@ -1634,9 +1787,23 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     // rows back in place (the residual stream IS the normalised tensor) next to the planes the products read.
     float* const ln_inplace = stable ? nullptr : (float*)hbuf;
     if (!stable) stream_norm(h->fln_g, h->fln_b, Mrows, xp_plane, ln_inplace);
+    // (pre-LN layers: gamma / beta of both norms live in the QKV / FFN1 weights -- fold_layer_norm at amx_create -- so a row pass
+    // normalises with (1, 0))
+    auto ln_finalize = [&]() {
+        Timed t_(h, AMX_KC_ROWNORM);
+        launch_ln_finalize((const float2*)ln_partial, D / 64, Mrows, c.eps, (float2*)ln_rowps, (float2*)ln_coef, s);
+    };
     for (int l = 0; l < c.layers; ++l) {
         const Layer& ly = h->layers[l];
-        if (stable) stream_norm(ly.ln1_g, ly.ln1_b, Mrows, xp_plane, nullptr);  // (completes the previous layer's FFN2 when that was deferred)
+        if (fold) {
+            // the first norm of the stack from the stream itself; later ones: the previous FFN2 left planes and statistics
+            if (l == 0) {
+                Timed t_(h, AMX_KC_ROWNORM);
+                launch_ln_rowprep(prec, (const float*)hbuf, D, Mrows, D, c.eps, xp, xp_plane, D, (float2*)ln_rowps, (float2*)ln_coef, s);
+            }
+        } else if (stable) {
+            stream_norm(h->unit_g, h->zero_b, Mrows, xp_plane, nullptr);  // (completes the previous layer's FFN2 when that was deferred)
+        }
         if (saved[l]) {
             // a classifier reads hidden state l (OUTPUT_l, acoustic_model.py:478-483): padded layout; with packed rows the padded
             // frames take their pre-encoder rows (finite, as meaningless as any padded frame) and the valid ones are scattered in
@@ -1649,16 +1816,9 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             }
         }
         {
-            GemmParams g{};
-            g.A = xp; g.a_plane = xp_plane; g.lda = D; g.rows_per_batch = Mrows;
-            g.W = ly.wqkv; g.w_plane = pln(h, (int64_t)3 * D * D); g.ldw = D;
-            g.M = (int)Mrows; g.N = 3 * D; g.K = D;
-            g.scale = ly.r_qkv; g.bias = ly.bqkv;
-            g.mode = 1; g.q = qb; g.k = kb; g.v = vtb;
-            g.qk_plane = qk_plane;
-            // packed rows: one "utterance" of Mp rows, so the scatter writes row m of head hh to [hh][m][:]
-            g.T = packed ? (int)std::max<int64_t>(Mp, 8) : T; g.Tp = packed ? TpTot : Tp; g.H = H; g.dh = 64;
-            { Timed t_(h, gemm_class(prec, g)); run_gemm(prec, g, s); }
+            GemmParams g = qkv_params(ly);
+            if (fold) g = as_consumer(g, ly.c_qkv);
+            { Timed t_(h, gemm_class(prec, g)); launch_gemm(prec, g, s); }
         }
         {
             AttnParams a{};
@@ -1671,36 +1831,26 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             a.order = packed ? (const int*)d_rowoff + N + 1 : nullptr;
             { Timed t_(h, AMX_KC_ATTENTION); launch_attention(prec, a, s); }
         }
-        {
-            GemmParams g{};
-            g.A = ao; g.a_plane = xp_plane; g.lda = D; g.rows_per_batch = Mrows;
-            g.W = ly.wo; g.w_plane = pln(h, (int64_t)D * D); g.ldw = D;
-            g.M = (int)Mrows; g.N = D; g.K = D;
-            g.scale = ly.r_o; g.bias = ly.bo;
-            g.residual = (const float*)hbuf; g.ldr = D; g.out_f32 = (float*)hbuf; g.ldo = D;
-            residual_gemm(g, true);
-        }
-        // pre-LN: the LayerNorm in front of the FFN (`final_layer_norm`); post-LN: `layer_norm` behind the attention residual
-        if (stable) stream_norm(ly.ln2_g, ly.ln2_b, Mrows, xp_plane, nullptr);
-        else stream_norm(ly.ln1_g, ly.ln1_b, Mrows, xp_plane, ln_inplace);
-        {
-            GemmParams g{};
-            g.A = xp; g.a_plane = xp_plane; g.lda = D; g.rows_per_batch = Mrows;
-            g.W = ly.w1; g.w_plane = pln(h, (int64_t)F * D); g.ldw = D;
-            g.M = (int)Mrows; g.N = F; g.K = D;
-            g.scale = ly.r_1; g.bias = ly.b1; g.act = 1;
-            g.out_p = ff; g.out_plane = pln(h, Mrows * F); g.ldp = F;
-            { Timed t_(h, gemm_class(prec, g)); run_gemm(prec, g, s); }
+        if (fold) {
+            residual_gemm(as_producer(oproj_params(ly)), false);
+            ln_finalize();
+        } else {
+            residual_gemm(oproj_params(ly), true);
+            // pre-LN: the LayerNorm in front of the FFN (`final_layer_norm`); post-LN: `layer_norm` behind the attention residual
+            if (stable) stream_norm(h->unit_g, h->zero_b, Mrows, xp_plane, nullptr);
+            else stream_norm(ly.ln1_g, ly.ln1_b, Mrows, xp_plane, ln_inplace);
         }
         {
-            GemmParams g{};
-            g.A = ff; g.a_plane = pln(h, Mrows * F); g.lda = F; g.rows_per_batch = Mrows;
-            g.W = ly.w2; g.w_plane = pln(h, (int64_t)D * F); g.ldw = F;
-            g.M = (int)Mrows; g.N = D; g.K = F;
-            g.scale = ly.r_2; g.bias = ly.b2;
-            g.residual = (const float*)hbuf; g.ldr = D; g.out_f32 = (float*)hbuf; g.ldo = D;
+            GemmParams g = ffn1_params(ly);
+            if (fold) g = as_consumer(g, ly.c_1);
+            { Timed t_(h, gemm_class(prec, g)); launch_gemm(prec, g, s); }
+        }
+        if (fold && l + 1 < c.layers) {
+            residual_gemm(as_producer(ffn2_params(ly)), false);
+            ln_finalize();
+        } else {
             // (the last layer of a packed batch is followed by the unpacking, not by a LayerNorm of these rows)
-            residual_gemm(g, !(packed && !packed_early && l == c.layers - 1));
+            residual_gemm(ffn2_params(ly), !fold && !(packed && !packed_early && l == c.layers - 1));
         }
         if (!stable) stream_norm(ly.ln2_g, ly.ln2_b, Mrows, xp_plane, ln_inplace);  // `final_layer_norm` closes the post-LN layer
     }

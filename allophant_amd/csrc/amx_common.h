@@ -275,6 +275,20 @@ struct GemmParams {
     int a_taps;
     int64_t a_tap_stride;
     unsigned long long* stamps;  // developer diagnostic (-DAMX_PP_STAMP builds of tools/gemm_bench.hip), else null
+    // ---- LayerNorm folded into the products around it (pre-LN encoder layers; ping-pong kernel only: gemm_ln_fold_ok()) ----
+    // LN(x) . W^T + b  =  rstd * ((x - p) . (gamma (.) W)^T) - rstd * (mu - p) * c + d   with c = W gamma, d = W beta + b, for
+    // ANY per-row pivot p.  PRODUCER (a residual product: out-projection, FFN2; ln_partial != null): besides the fp32 stream
+    // v = acc * scale + bias + residual it writes the planes out_p of u = (v - p_m) * s_m -- pivot and power-of-two scale of row m
+    // from ln_rowps, what the row's PREVIOUS statistics gave -- and, per row and 64-column block, (sum, sum of squares about the
+    // block's own mean) of v - p_m into ln_partial[m * (N / 64) + block]: fixed slots, no atomics, so results stay bitwise
+    // reproducible.  launch_ln_finalize() merges the blocks (Chan's update: no E[x^2] - E[x]^2 cancellation however far the pivot
+    // is from the mean) into row_coef[m] = (rstd / s_m, -rstd * (mu - p_m)) and moves ln_rowps on.  CONSUMER (QKV, FFN1;
+    // row_coef != null): A = the planes of u, W = gamma (.) W packed at amx_create, bias = d, and the epilogue computes
+    // v = alpha_m * (acc * scale) + beta_m * col_c[n] + bias[n].
+    const float2* ln_rowps;   // producer: [M] (pivot, scale)
+    float2* ln_partial;       // producer: [M][N / 64]
+    const float2* row_coef;   // consumer: [M] (alpha, beta)
+    const float* col_c;       // consumer: [N]
 };
 
 extern bool g_force_generic_gemm;
@@ -295,6 +309,9 @@ int gemm_planned_splits(int prec, const GemmParams& p);
 bool fixup_rownorm_eligible(const GemmParams& p);
 void launch_fixup_rownorm(int prec, const GemmParams& p, int splits, const float* gamma, const float* beta, float eps, void* out_p,
                           int64_t out_plane, int64_t ldp, float* out_ln, int64_t ldo_ln, hipStream_t stream);
+// true when launch_gemm runs this product -- a producer (ln_partial set) or a consumer (row_coef set) of the LayerNorm fold -- on
+// the ping-pong kernel in one piece (no K chunks), the only place the fold's epilogues exist
+bool gemm_ln_fold_ok(int prec, const GemmParams& p);
 // same kernel with grid.z = groups (per-group pointer advances za/zw/zbias/zout/zoutp); requires N <= 64
 void launch_gemm_grouped(int prec, const GemmParams& p, int groups, hipStream_t stream);
 
@@ -357,6 +374,15 @@ void launch_pack_rows(const float* padded, float* packed, const int* row_off, co
 void launch_rownorm(int prec, const float* x, int64_t ldx, int64_t M, int D, const float* gamma1, const float* beta1,
                     int gelu, const float* gamma2, const float* beta2, float eps1, float eps2, void* out_p,
                     int64_t out_plane, int64_t ldp, float* out_f32, int64_t ldo, hipStream_t s);
+// LayerNorm fold (GemmParams.ln_partial / row_coef): the FIRST norm of the encoder stack, from the fp32 stream itself: exact row
+// statistics (two passes over the row in registers, like launch_rownorm) -> planes of u = (x - mu) * s with s the power of two
+// that puts 16 / sigma ... 8 / sigma into it, rowps[m] = (mu, s), coef[m] = (rstd / s, 0)
+void launch_ln_rowprep(int prec, const float* x, int64_t ldx, int64_t M, int D, float eps, void* out_p, int64_t out_plane, int64_t ldp,
+                       float2* rowps, float2* coef, hipStream_t s);
+// merges the per-block statistics a producer left in `partial` [M][blocks] (of v - pivot, 64 columns per block) into
+// coef[m] = (rstd / s_m, -rstd * (mu - p_m)) for the consumer of those planes, then moves rowps[m] on to (mu, scale of the new rstd)
+// for the next producer
+void launch_ln_finalize(const float2* partial, int blocks, int64_t M, float eps, float2* rowps, float2* coef, hipStream_t s);
 // the same with the rows of a ragged batch gathered on the way out: input row n * T_rows + t -> plane row row_off[n] + t,
 // frames t >= frame_len[n] dropped (the feature projection of a ragged batch then runs on the valid frames only)
 void launch_rownorm_to_packed(int prec, const float* x, int64_t ldx, int64_t M, int D, const float* gamma1, const float* beta1,

@@ -418,6 +418,28 @@ bool gemm_uses_pp(int prec, const GemmParams& p_in) {
     return pp_eligible(NT, p) && !dma_preferred_shape(NT, p);  // the routing of launch_gemm_t
 }
 
+bool gemm_ln_fold_ok(int prec, const GemmParams& p_in) {
+    const GemmParams p = with_vec_flag(p_in);
+    const int NT = prec_planes(prec);
+    if (!p.vec_ok || !pp_eligible(NT, p) || dma_preferred_shape(NT, p)) return false;
+    int mi, splits, ni;
+    pp_plan(NT, p, &mi, &splits, &ni);
+    if (splits != 1) return false;
+    if (p.ln_partial) {
+        // producer: fp32 stream + residual, planes of the new rows, whole 64-column blocks, 256-column tiles
+        if (ni != 4 || p.N % 64 || p.N > 1024 || !p.out_f32 || !p.residual || !p.out_p || !p.ln_rowps || p.act || p.mode || p.row_len ||
+            p.row_coef)
+            return false;
+        if (NT == 2 && (p.out_plane != PLANE_IL || p.ldp % 32)) return false;
+        if (p.ldp % 8 || ((uintptr_t)p.out_p & 15) || ((uintptr_t)p.ln_partial & 7) || ((uintptr_t)p.ln_rowps & 7)) return false;
+    }
+    if (p.row_coef) {
+        if (!p.col_c || ((uintptr_t)p.col_c & 15) || ((uintptr_t)p.row_coef & 7) || p.residual || p.row_len) return false;
+        if (p.mode != 1 && (!p.out_p || p.out_f32)) return false;
+    }
+    return true;
+}
+
 int gemm_planned_splits(int prec, const GemmParams& p_in) {
     const GemmParams p = with_vec_flag(p_in);
     if (p.ln_gamma) return 1;

@@ -917,6 +917,102 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* x, int64_t ld
 }
 
 // ----------------------------------------------------------------------------------------------------------------
+// LayerNorm fold (GemmParams.ln_partial / row_coef, amx_common.h).  The power of two a row's planes are written under: 16 * rstd
+// rounded down to a power of two, i.e. sigma * s in (8, 16] -- |x - mu| <= sqrt(D) sigma keeps a row itself below 512, and the NEXT
+// state of the row (written under this scale before its own statistics are known) may grow a hundredfold before an fp16 plane
+// overflows (which the range report of the pass would then show); values below 2^-6 sigma lose bits of their lo plane.
+// ----------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float ln_plane_scale(float rstd) {
+    const float t = fminf(fmaxf(16.0f * rstd, 1.0e-12f), 1.0e12f);
+    return __uint_as_float(__float_as_uint(t) & 0x7F800000u);
+}
+
+// the first norm of the stack: exact statistics from the fp32 row (the arithmetic of rownorm_kernel), planes of (x - mu) * s
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void ln_rowprep_kernel(const float* __restrict__ x, int64_t ldx, int64_t M, int D, float eps,
+                                                         T* __restrict__ out_p, int64_t out_plane, int64_t ldp,
+                                                         float2* __restrict__ rowps, float2* __restrict__ coef) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* src = x + row * ldx;
+    float4 v[4];
+    const float invD = 1.0f / (float)D;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        v[i] = c < D ? *(const float4*)(src + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += v[i].x + v[i].y + v[i].z + v[i].w;
+    const float mu = wave_sum(s) * invD;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+            const float dx = v[i].x - mu, dy = v[i].y - mu, dz = v[i].z - mu, dw = v[i].w - mu;
+            q += dx * dx + dy * dy + dz * dz + dw * dw;
+        }
+    }
+    const float rs = 1.0f / sqrtf(wave_sum(q) * invD + eps);
+    const float sc = ln_plane_scale(rs);
+    if (lane == 0) {
+        rowps[row] = make_float2(mu, sc);
+        coef[row] = make_float2(rs / sc, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+            T hi[4], lo[4];
+            split16<T, NT>((v[i].x - mu) * sc, hi[0], lo[0]);
+            split16<T, NT>((v[i].y - mu) * sc, hi[1], lo[1]);
+            split16<T, NT>((v[i].z - mu) * sc, hi[2], lo[2]);
+            split16<T, NT>((v[i].w - mu) * sc, hi[3], lo[3]);
+            T* dst = out_p + pidx(row * ldp + c, plane_is_il<NT>(out_plane));
+            typedef typename Vec4<T>::type V4;
+            V4 hv = {hi[0], hi[1], hi[2], hi[3]};
+            *(V4*)dst = hv;
+            if (NT > 1) {
+                V4 lv = {lo[0], lo[1], lo[2], lo[3]};
+                *(V4*)(dst + out_plane) = lv;
+            }
+        }
+    }
+}
+
+// one thread per row: Chan's pairwise update over the row's 64-column blocks, in ascending order
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float2* __restrict__ partial, int blocks, int64_t M, float eps,
+                                                          float2* __restrict__ rowps, float2* __restrict__ coef) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= M) return;
+    const float2* pr = partial + row * blocks;
+    float2 b[16];
+    float s1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        if (j < blocks) {
+            b[j] = pr[j];
+            s1 += b[j].x;
+        }
+    const float invD = 1.0f / (float)(blocks * 64);
+    const float m1 = s1 * invD;  // mean of x - pivot
+    float m2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        if (j < blocks) {
+            const float d = b[j].x * (1.0f / 64.0f) - m1;
+            m2 += fmaf(64.0f * d, d, b[j].y);
+        }
+    const float rs = 1.0f / sqrtf(m2 * invD + eps);
+    const float2 ps = rowps[row];
+    coef[row] = make_float2(rs / ps.y, -rs * m1);
+    rowps[row] = make_float2(ps.x + m1, ln_plane_scale(rs));
+}
+
+// ----------------------------------------------------------------------------------------------------------------
 // positional-conv input image: h[N*T, D] fp32 -> planes [G][N][Tpad][cg], zero rows in front/behind every utterance
 // ----------------------------------------------------------------------------------------------------------------
 template <typename T, int NT>
@@ -1521,6 +1617,21 @@ void launch_rownorm(int prec, const float* x, int64_t ldx, int64_t M, int D, con
     dim3 grid((unsigned)((M + 3) / 4));
     AMX_DISPATCH(prec, hipLaunchKernelGGL((rownorm_kernel<T16, NT>), grid, dim3(256), 0, s, x, ldx, M, D, gamma1, beta1, gelu,
                                           gamma2, beta2, eps1, eps2, (T16*)out_p, out_plane, ldp, out_f32, ldo, nullptr, nullptr, 1));
+}
+
+void launch_ln_rowprep(int prec, const float* x, int64_t ldx, int64_t M, int D, float eps, void* out_p, int64_t out_plane, int64_t ldp,
+                       float2* rowps, float2* coef, hipStream_t s) {
+    dim3 grid((unsigned)((M + 3) / 4));
+    switch (prec) {
+        case PREC_BF16: hipLaunchKernelGGL((ln_rowprep_kernel<bf16, 1>), grid, dim3(256), 0, s, x, ldx, M, D, eps, (bf16*)out_p, out_plane, ldp, rowps, coef); break;
+        case PREC_F16: hipLaunchKernelGGL((ln_rowprep_kernel<f16, 1>), grid, dim3(256), 0, s, x, ldx, M, D, eps, (f16*)out_p, out_plane, ldp, rowps, coef); break;
+        case PREC_BF16X3: hipLaunchKernelGGL((ln_rowprep_kernel<bf16, 2>), grid, dim3(256), 0, s, x, ldx, M, D, eps, (bf16*)out_p, out_plane, ldp, rowps, coef); break;
+        default: hipLaunchKernelGGL((ln_rowprep_kernel<f16, 2>), grid, dim3(256), 0, s, x, ldx, M, D, eps, (f16*)out_p, out_plane, ldp, rowps, coef); break;
+    }
+}
+
+void launch_ln_finalize(const float2* partial, int blocks, int64_t M, float eps, float2* rowps, float2* coef, hipStream_t s) {
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, partial, blocks, M, eps, rowps, coef);
 }
 
 void launch_rownorm_to_packed(int prec, const float* x, int64_t ldx, int64_t M, int D, const float* gamma1, const float* beta1,
