@@ -193,7 +193,9 @@ struct amx_handle_s {
     int64_t range_carry = 0;  // count of a slot that had to be reused before any call had read it
     // last forward geometry
     int last_N = 0;
-    bool last_fold = false;  // the last pass ran its encoder layers with the LayerNorm fold (reported by amx_graph_info's sibling below)
+    bool last_fold = false;  // amx_pass_info: the last pass ran its encoder layers with the LayerNorm fold ...
+    int last_packed = 0, last_graph = 0;  // ... on packed rows (1; 2: from the feature projection on); eager / recorded / replayed
+    int64_t last_rows = 0;
     bool qkv_dirty = false;
     int64_t last_L = 0, last_T = 0;
     bool last_keep = false;
@@ -1590,6 +1592,9 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
                gemm_ln_fold_ok(prec, as_consumer(ffn1_params(ly), ly.c_1)) && gemm_ln_fold_ok(prec, as_producer(ffn2_params(ly)));
     }
     h->last_fold = fold;
+    h->last_packed = packed_early ? 2 : (packed ? 1 : 0);
+    h->last_rows = Mrows;
+    h->last_graph = 0;
     void* const hbuf_plan = hbuf;
 
     // =============================================================================================================
@@ -1944,6 +1949,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
                 HIPCHK(h, hipGraphLaunch(g.exec, s));
                 g.last_use = ++h->graph_clock;
                 ++h->graph_replays;
+                h->last_graph = 2;
                 done = true;
                 break;
             }
@@ -1980,6 +1986,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
                     entry.last_use = ++h->graph_clock;
                     h->graphs.push_back(std::move(entry));
                     ++h->graph_captures;
+                    h->last_graph = 1;
                     done = true;
                 } else {
                     if (graph) (void)hipGraphDestroy(graph);
@@ -2011,6 +2018,14 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     }
     h->qkv_dirty = packed;  // a packed call leaves other rows in the Q / K / V planes: the next padded call re-zeroes them
 #undef WS
+    return AMX_OK;
+}
+
+extern "C" int amx_pass_info(amx_handle h, int32_t* info, int n) {
+    if (!h || !info || n < 0) return AMX_EINVAL;
+    const int32_t values[AMX_PASS_INFO_COUNT] = {h->last_fold ? 1 : 0, h->last_packed, h->last_graph,
+                                                 (int32_t)std::min<int64_t>(h->last_rows, INT32_MAX)};
+    for (int i = 0; i < n && i < AMX_PASS_INFO_COUNT; ++i) info[i] = values[i];
     return AMX_OK;
 }
 

@@ -83,9 +83,20 @@ class Predictions:
     _geometry: Optional[Tuple[int, int]] = dataclasses.field(default=None, repr=False, compare=False)
     # the `target_feature_indices` the outputs were computed under (their phoneme block is that many phones wide)
     _inventory: Optional[Tensor] = dataclasses.field(default=None, repr=False, compare=False)
+    # assembled by parallel.gather_flat_predictions: one status word per rank (device tensor; non-zero = that rank reported a
+    # range error -- AMX_ERANGE -- with its shard).  Left on the device so that the gather never synchronises the host.
+    _status: Optional[Tensor] = dataclasses.field(default=None, repr=False, compare=False)
 
     def __len__(self) -> int:
         return len(self.lengths)
+
+    def check_ranks(self) -> None:
+        """Data-parallel predictions only: raises ``FloatingPointError`` if a rank reported activations beyond the range of the
+        planes with the shard it contributed (reads one small tensor back: call it where the host reads the results anyway)."""
+        if self._status is not None:
+            bad = [r for r, st in enumerate(self._status.tolist()) if st]
+            if bad:
+                raise FloatingPointError(f"rank(s) {bad} reported a range error (AMX_ERANGE) with their shard of this batch")
 
     def task_count(self) -> int:
         return len(self.outputs)
@@ -463,6 +474,17 @@ class Estimator:
         captures, replays = C.c_int64(0), C.c_int64(0)
         _lib.check(self._lib, self._handle, self._lib.amx_graph_info(self._handle, C.byref(captures), C.byref(replays)))
         return int(captures.value), int(replays.value)
+
+    def pass_info(self) -> Dict[str, int]:
+        """Which optional forms the last ``predict`` took (``amx_pass_info``): ``ln_fold`` 1 = LayerNorm folded into the encoder
+        products, ``packed`` 0 / 1 / 2 = padded rows / packed layers / packed from the feature projection on, ``graph`` 0 / 1 / 2
+        = eager / recorded / replayed, ``rows`` = frames the encoder layers worked on."""
+        if _lib.AMX_ABI_VERSION < 6:
+            return {}
+        n = len(_lib.PASS_INFO)
+        info = (C.c_int32 * n)()
+        _lib.check(self._lib, self._handle, self._lib.amx_pass_info(self._handle, info, n))
+        return {k: int(info[i]) for i, k in enumerate(_lib.PASS_INFO)}
 
     def check_finite(self) -> None:
         """Range check of the last ``predict`` (``amx_check_finite``; no upstream counterpart -- the reference computes in

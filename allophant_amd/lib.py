@@ -10,8 +10,8 @@ import os
 from typing import Optional
 
 # AMX_ABI_OVERRIDE: developer switch for same-box A/B runs against a library built from an OLDER revision (tools/ab_build.sh):
-# ABI 5 added flags and entry points to ABI 4 without changing a struct, so an ABI-4 build runs under this binding
-AMX_ABI_VERSION = int(os.environ.get("AMX_ABI_OVERRIDE") or 5)
+# ABI 5 and 6 added flags and entry points to ABI 4 without changing a struct, so an older build runs under this binding
+AMX_ABI_VERSION = int(os.environ.get("AMX_ABI_OVERRIDE") or 6)
 AMX_MAX_CONV = 8
 AMX_MAX_DEPS = 64
 AMX_NAME_LEN = 48
@@ -21,6 +21,7 @@ PRECISIONS = {"bf16": 0, "f16": 1, "bf16x3": 2, "f16x3": 3}
 FLAG_HOST_IO, FLAG_RAW_LOGITS, FLAG_KEEP_HIDDEN, FLAG_TIMING, FLAG_PADDED, FLAG_NO_PACK, FLAG_CONTINUE = 1, 2, 4, 8, 16, 32, 64
 FLAG_NO_GRAPH, FLAG_NO_RANGE_CHECK = 128, 256
 NORM_LAYER, NORM_GROUP = 0, 1
+PASS_INFO = ["ln_fold", "packed", "graph", "rows"]  # AMX_PASS_INFO_*
 KERNEL_CLASSES = ["gemm_pp", "gemm_tile", "attention", "rownorm", "conv0", "other", "gemm_ln", "conv_tail"]
 DEP_OUTPUT = -1
 
@@ -33,7 +34,7 @@ EXPORTS = [
     "amx_create", "amx_destroy", "amx_last_error", "amx_set_inventory", "amx_output_layout", "amx_forward",
     "amx_synchronize", "amx_greedy_ctc", "amx_debug_fetch", "amx_device_bytes", "amx_timing_fetch",
     "amx_max_utterances", "amx_greedy_ctc_emissions", "amx_check_finite", "amx_gather_outputs", "amx_dist_last_error",
-    "amx_graph_info",
+    "amx_graph_info", "amx_pass_info",
 ]
 
 
@@ -102,6 +103,9 @@ def load() -> C.CDLL:
     if hasattr(lib, "amx_graph_info") or AMX_ABI_VERSION >= 5:  # (absent from an ABI-4 build under AMX_ABI_OVERRIDE)
         lib.amx_graph_info.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
         lib.amx_graph_info.restype = i32
+    if hasattr(lib, "amx_pass_info") or AMX_ABI_VERSION >= 6:  # (absent from older builds under AMX_ABI_OVERRIDE)
+        lib.amx_pass_info.argtypes = [vp, C.POINTER(C.c_int32), i32]
+        lib.amx_pass_info.restype = i32
     lib.amx_check_finite.argtypes = [vp, vp, C.POINTER(i64)]
     lib.amx_check_finite.restype = i32
     lib.amx_greedy_ctc.argtypes = [vp, vp, C.POINTER(i64), i32, i64, vp, vp, vp, vp, vp]

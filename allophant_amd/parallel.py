@@ -39,18 +39,30 @@ def padding_sensitive(spec) -> bool:
     return spec.get("feat_extract_norm", "layer") == "group" or not spec.get("use_attention_mask", True)
 
 
-def shard_batch(batch: Batch, rank: int, world: int, keep_length: bool = False) -> Optional[Batch]:
-    """Block ``rank`` of ``batch``, re-padded to its own longest utterance (the reference requires
-    ``L == max(lengths)``, utils.py:62-63).  Returns ``None`` for an empty block.
+def _keep_length(spec, keep_length: Optional[bool]) -> bool:
+    """The padded length a shard keeps: an explicit ``keep_length`` wins, otherwise the model's ``spec`` decides
+    (``padding_sensitive``).  Neither given is an error: the silent default used to be "re-pad", which is wrong for the
+    padding-sensitive variants by 0.5-0.9 in log-probability (round-5 advisor finding)."""
+    if keep_length is not None:
+        return bool(keep_length)
+    if spec is None:
+        raise TypeError("shard_batch / data_parallel_predict need the model's `spec` (or an explicit `keep_length`): whether a "
+                        "shard may be re-padded to its own longest utterance depends on the encoder variant (padding_sensitive)")
+    return padding_sensitive(spec)
 
-    ``keep_length=True`` keeps the padded length of the GLOBAL batch instead (the block is marked as a slice of a larger
-    batch and ``Estimator.predict`` runs it with ``AMX_FLAG_PADDED``): required for ``padding_sensitive`` specs, whose
-    single-device result depends on that length -- with re-padded blocks the data-parallel output would differ from it."""
+
+def shard_batch(batch: Batch, rank: int, world: int, spec=None, keep_length: Optional[bool] = None) -> Optional[Batch]:
+    """Block ``rank`` of ``batch``.  For the released (XLS-R) form the block is re-padded to its own longest utterance (the
+    reference requires ``L == max(lengths)``, utils.py:62-63); for ``padding_sensitive(spec)`` variants it keeps the padded
+    length of the GLOBAL batch (the block is marked as a slice of a larger batch and ``Estimator.predict`` runs it with
+    ``AMX_FLAG_PADDED``), because their single-device result depends on that length.  ``spec`` is the model's spec
+    (``Estimator.spec``); ``keep_length`` overrides what it implies.  Returns ``None`` for an empty block."""
+    keep = _keep_length(spec, keep_length)
     lo, hi = shard_bounds(len(batch), world)[rank]
     if hi <= lo:
         return None
     lengths = batch.lengths[lo:hi]
-    if keep_length:
+    if keep:
         local = Batch(batch.audio_features[lo:hi].contiguous(), lengths, batch.language_ids[lo:hi])
         local._padded = True
         return local
@@ -58,14 +70,47 @@ def shard_batch(batch: Batch, rank: int, world: int, keep_length: bool = False) 
     return Batch(batch.audio_features[lo:hi, :local_max].contiguous(), lengths, batch.language_ids[lo:hi])
 
 
+class RankError(FloatingPointError):
+    """Raised on the destination rank when another rank reported a range error with its shard (and on that rank itself)."""
+
+
+def predict_reporting(predict: Callable[[Batch], Predictions], batch: Batch, retries: int = 8):
+    """``predict(batch)`` for a rank of a data-parallel job: returns ``(predictions, error)``.
+
+    ``Estimator.predict`` raises ``FloatingPointError`` (``AMX_ERANGE``) when an EARLIER pass left the range of the planes, before
+    anything of the current call has been enqueued.  Raised on one rank only, in front of a collective, that leaves every
+    other rank blocked in the gather (round-5 advisor finding).  Here the report is caught, the pass is issued again (the
+    report was consumed by the call that raised it), and the error is handed to the caller, which first joins the step's
+    collectives -- its status travels with the frame lengths -- and raises afterwards."""
+    error: Optional[BaseException] = None
+    for _ in range(retries):
+        try:
+            return predict(batch), error
+        except FloatingPointError as exc:
+            error = exc
+    raise error  # every retry reported again: nothing sensible can be sent
+
+
+def _raise_reported(statuses: List[int], own: Optional[BaseException]) -> None:
+    bad = [r for r, st in enumerate(statuses) if st]
+    if own is not None:
+        raise own
+    if bad:
+        raise RankError(f"rank(s) {bad} reported activations beyond the range of the 16-bit planes in an earlier pass of their "
+                        "shard (AMX_ERANGE): the gathered predictions of that pass are not to be trusted; precision='bf16x3' "
+                        "has the range of fp32")
+
+
 def gather_predictions(local: Optional[Predictions], names_and_classes: List[Tuple[str, int]], total_utterances: int,
                        device: torch.device, dst: int = 0, group=None,
-                       aliases: Optional[Dict[str, str]] = None, frames: Optional[int] = None) -> Optional[Predictions]:
+                       aliases: Optional[Dict[str, str]] = None, frames: Optional[int] = None,
+                       error: Optional[BaseException] = None) -> Optional[Predictions]:
     """Gathers per-rank ``Predictions`` to ``dst``: one ``gather`` of a packed ``[T_max, n_max, sum(C)]`` fp32 block per
     rank and one of the int64 frame lengths.  Returns the assembled ``Predictions`` ([T_max, N, C] per output, frames
     beyond an utterance's length are zero) on ``dst`` and ``None`` elsewhere.  ``frames``: the padded frame count of the
     global batch when the caller knows it (``spec.frame_lengths([L], spec)``): the ranks then need not agree on it with an
-    ``all_reduce`` whose result the host reads back."""
+    ``all_reduce`` whose result the host reads back.  ``error``: what ``predict_reporting`` caught on this rank -- it travels
+    as a status word behind the frame lengths, the rank raises it AFTER the collectives and ``dst`` raises ``RankError``."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     bounds = shard_bounds(total_utterances, world)
@@ -85,7 +130,9 @@ def gather_predictions(local: Optional[Predictions], names_and_classes: List[Tup
         t_max = int(t_tensor.item())
 
     packed = torch.zeros(t_max, n_max, total_c, dtype=torch.float32, device=device)
-    lengths = torch.zeros(n_max, dtype=torch.int64, device=device)
+    lengths = torch.zeros(n_max + 1, dtype=torch.int64, device=device)  # [n_max] = this rank's status
+    if error is not None:
+        lengths[n_max] = 1
     if local is not None:
         n_local = len(local.lengths)
         col = 0
@@ -99,7 +146,9 @@ def gather_predictions(local: Optional[Predictions], names_and_classes: List[Tup
     dist.gather(packed, gathered_p, dst=dst, group=group)
     dist.gather(lengths, gathered_l, dst=dst, group=group)
     if rank != dst:
+        _raise_reported([], error)
         return None
+    _raise_reported([int(gathered_l[r][n_max]) for r in range(world)], error)
     outputs: Dict[str, Tensor] = {}
     all_lengths = torch.cat([gathered_l[r][: hi - lo] for r, (lo, hi) in enumerate(bounds)])
     col = 0
@@ -121,19 +170,21 @@ def gather_predictions(local: Optional[Predictions], names_and_classes: List[Tup
 
 def data_parallel_predict(predict: Callable[[Batch], Predictions], batch: Batch, outputs: List[Tuple[str, int]],
                           device: torch.device, dst: int = 0, group=None,
-                          aliases: Optional[Dict[str, str]] = None, keep_length: bool = False) -> Optional[Predictions]:
+                          aliases: Optional[Dict[str, str]] = None, spec=None,
+                          keep_length: Optional[bool] = None) -> Optional[Predictions]:
     """One data-parallel ``predict`` over the ranks of ``group``: every rank takes its contiguous block of utterances
     (``shard_batch``), runs ``predict`` on it (e.g. ``lambda b: estimator.predict(b.to(device), tfi)``) and the
     log-probabilities are gathered to ``dst`` (``gather_predictions``), which gets the ``Predictions`` of the whole batch;
     the other ranks get ``None``.  ``outputs`` lists the distinct outputs as (name, classes) in output order and
     ``aliases`` the names that share storage with one of them (see ``unique_outputs``): a rank whose block is empty has no
-    local prediction to read them from.  ``keep_length``: pass ``padding_sensitive(spec)`` -- the blocks then keep the padded
-    length of the global batch (see ``shard_batch``)."""
+    local prediction to read them from.  ``spec``: the model's spec (``Estimator.spec``) -- decides whether the blocks keep
+    the padded length of the global batch (``padding_sensitive``; ``keep_length`` overrides).  A range report
+    (``FloatingPointError``) on one rank does not strand the others: see ``predict_reporting``."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    local_batch = shard_batch(batch, rank, world, keep_length=keep_length)
-    local = predict(local_batch) if local_batch is not None else None
-    return gather_predictions(local, outputs, len(batch), device, dst=dst, group=group, aliases=aliases)
+    local_batch = shard_batch(batch, rank, world, spec=spec, keep_length=keep_length)
+    local, error = predict_reporting(predict, local_batch) if local_batch is not None else (None, None)
+    return gather_predictions(local, outputs, len(batch), device, dst=dst, group=group, aliases=aliases, error=error)
 
 
 class PendingGather:
@@ -142,14 +193,17 @@ class PendingGather:
     the current stream wait for them and returns the assembled ``Predictions`` on the destination rank, ``None`` elsewhere.
     The handle keeps the send buffers alive until then."""
 
-    def __init__(self, works, keep, assemble):
-        self._works, self._keep, self._assemble = works, keep, assemble
+    def __init__(self, works, keep, assemble, error: Optional[BaseException] = None):
+        self._works, self._keep, self._assemble, self._error = works, keep, assemble, error
 
     def wait(self) -> Optional[Predictions]:
         for work in self._works:
             work.wait()
         result = self._assemble() if self._assemble is not None else None
+        error, self._error = self._error, None
         self._works, self._keep, self._assemble = [], None, None
+        if error is not None:
+            raise error  # this rank's own range report: it has joined the collectives of the step, now it says so
         return result
 
 
@@ -167,12 +221,15 @@ class _CompletedGather:
         return result
 
 
-def gather_flat_predictions(local: Predictions, device: torch.device, dst: int = 0, group=None, async_op: bool = False):
+def gather_flat_predictions(local: Predictions, device: torch.device, dst: int = 0, group=None, async_op: bool = False,
+                            error: Optional[BaseException] = None):
     """Fast path for equal-shaped shards (every rank ran the same ``(N, L)`` geometry, e.g. the weak-scaling benchmark):
     the outputs of ``Estimator.predict`` are views of one flat fp32 block, so a single ``gather`` of that block (plus one
     of the frame lengths) moves everything; rank ``dst`` re-assembles ``[T, world * N, C]`` per output with one strided
     copy each.  Returns the assembled ``Predictions`` on ``dst`` and ``None`` elsewhere -- or, with ``async_op=True``, a
-    ``PendingGather`` whose ``wait()`` returns that."""
+    ``PendingGather`` whose ``wait()`` returns that.  ``error`` (``predict_reporting``): sent as a status word behind the frame
+    lengths; this rank raises it when the gather is waited for, ``dst`` raises ``RankError``.  With ``Predictions.lengths`` on the
+    host (the façade's default) the status of the OTHER ranks is read on ``dst`` in ``wait()``, which has synchronised anyway."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     flat = local._flat
@@ -181,8 +238,8 @@ def gather_flat_predictions(local: Predictions, device: torch.device, dst: int =
     n = len(local.lengths)
     stacked = torch.empty(world, flat.numel(), dtype=flat.dtype, device=device) if rank == dst else None
     w1 = dist.gather(flat, [stacked[r] for r in range(world)] if rank == dst else None, dst=dst, group=group, async_op=True)
-    lens = local.lengths.to(device)
-    all_lens = torch.empty(world, n, dtype=lens.dtype, device=device) if rank == dst else None
+    lens = torch.cat((local.lengths.to(device), torch.tensor([0 if error is None else 1], dtype=local.lengths.dtype, device=device)))
+    all_lens = torch.empty(world, n + 1, dtype=lens.dtype, device=device) if rank == dst else None
     w2 = dist.gather(lens, [all_lens[r] for r in range(world)] if rank == dst else None, dst=dst, group=group, async_op=True)
 
     def assemble() -> Predictions:
@@ -200,9 +257,9 @@ def gather_flat_predictions(local: Predictions, device: torch.device, dst: int =
             outputs[name] = block.permute(1, 0, 2, 3).reshape(t, world * n, c)
             done[key] = name
         # frame lengths stay on `device`: a host copy here would serialise the caller with the stream every step
-        return Predictions(outputs, all_lens.reshape(-1))
+        return Predictions(outputs, all_lens[:, :n].reshape(-1), _status=all_lens[:, n])
 
-    pending = PendingGather([w1, w2], (flat, lens, stacked, all_lens), assemble if rank == dst else None)
+    pending = PendingGather([w1, w2], (flat, lens, stacked, all_lens), assemble if rank == dst else None, error)
     return pending if async_op else pending.wait()
 
 
@@ -252,7 +309,7 @@ class DataParallelRunner:
         lo_size, lo_count = -int(probe[1]), -int(probe[3])
         return lo_size >= 0 and lo_size == int(probe[0]) and lo_count == int(probe[2])
 
-    def _padded(self, local: Optional[Predictions], total: Optional[int]) -> Optional[Predictions]:
+    def _padded(self, local: Optional[Predictions], total: Optional[int], error: Optional[BaseException] = None) -> Optional[Predictions]:
         if local is not None and self._outputs is None:
             self._outputs, self._aliases = unique_outputs(local)
         if self._outputs is None:
@@ -261,7 +318,7 @@ class DataParallelRunner:
         if total is None:
             raise ValueError("shards of different shapes need the padded gather: pass total_utterances")
         result = gather_predictions(local, self._outputs, total, self._device, dst=self._dst, group=self._group,
-                                    aliases=self._aliases)
+                                    aliases=self._aliases, error=error)
         self.completed += 1
         return result
 
@@ -273,21 +330,22 @@ class DataParallelRunner:
     def step(self, local_batch: Optional[Batch], total_utterances: Optional[int] = None) -> Optional[Predictions]:
         """``total_utterances``: size of THIS step's global batch (default: the constructor's), used by the padded gather."""
         total = self._total if total_utterances is None else int(total_utterances)
-        local = self._predict(local_batch) if local_batch is not None else None
+        # (a range report of an earlier pass -- FloatingPointError -- must not keep this rank out of the step's collectives)
+        local, error = predict_reporting(self._predict, local_batch) if local_batch is not None else (None, None)
         if not self._flat:
-            return self._padded(local, total)
+            return self._padded(local, total, error)
         if self._verify and not self._same_geometry(local):
             # the flat gather cannot take this step: complete what is in flight first (order on rank `dst`), then gather
             # padded.  The in-flight gather is the PREVIOUS step's result and is what this call returns; this step's own
             # result is complete as well and is parked for the next step() / drain().
             had_pending = self._pending is not None
             previous = self.drain()
-            result = self._padded(local, total)
+            result = self._padded(local, total, error)
             if not had_pending:
                 return result
             self._pending = _CompletedGather(result)
             return previous
-        handle = gather_flat_predictions(local, self._device, dst=self._dst, group=self._group, async_op=True)
+        handle = gather_flat_predictions(local, self._device, dst=self._dst, group=self._group, async_op=True, error=error)
         if not self._overlap:
             self.completed += 1
             return handle.wait()

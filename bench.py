@@ -542,7 +542,7 @@ def main():
     global_batch = Batch(audio, lengths, torch.zeros(n_global, dtype=torch.long))
     if world > 1:
         # (group-norm / unmasked variants: the shards keep the global padded length -- parallel.padding_sensitive)
-        shard = parallel.shard_batch(global_batch, rank, world, keep_length=parallel.padding_sensitive(spec))
+        shard = parallel.shard_batch(global_batch, rank, world, spec=spec)
         if shard is None:
             raise SystemExit("more ranks than utterances")
         bounds = parallel.shard_bounds(n_global, world)

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define AMX_ABI_VERSION 5
+#define AMX_ABI_VERSION 6
 
 #define AMX_MAX_CONV 8
 #define AMX_MAX_DEPS 64
@@ -199,6 +199,15 @@ int amx_forward(amx_handle h, const float* audio, const int64_t* lengths, int N,
 int amx_synchronize(amx_handle h, void* stream);
 /* number of forward passes recorded into HIP graphs / replayed from one so far (measurement and test hook) */
 int amx_graph_info(amx_handle h, int64_t* captures, int64_t* replays);
+
+/* Which of the plan's optional forms the last amx_forward took (ABI 6; measurement and test hook -- results do not depend on them
+ * beyond rounding): fills info[0 .. min(n, AMX_PASS_INFO_COUNT)). */
+#define AMX_PASS_INFO_LN_FOLD 0   /* 1: pre-LN encoder layers with their LayerNorm passes folded into the products around them */
+#define AMX_PASS_INFO_PACKED 1    /* 0: padded rows; 1: encoder layers on the valid frames only; 2: packed from the feature projection on */
+#define AMX_PASS_INFO_GRAPH 2     /* 0: enqueued launch by launch; 1: recorded into a HIP graph by this call; 2: replayed from one */
+#define AMX_PASS_INFO_ROWS 3      /* rows (frames) the encoder layers worked on */
+#define AMX_PASS_INFO_COUNT 4
+int amx_pass_info(amx_handle h, int32_t* info, int n);
 
 /* Range check of the last amx_forward on `stream` (no upstream counterpart: the reference computes in fp32).  The 16-bit
  * planes of the fp16 modes hold |x| <= 65504; weights are packed under a per-tensor power-of-two scale, so only an

@@ -46,9 +46,9 @@ def _worker(rank, world, port, result_path):
     full = Batch(audio, lengths, torch.zeros(len(lengths), dtype=torch.long))
     names = [(n, c) for n, c in [("syllabic", 4), ("long", 4), ("phoneme", 7)]]
     gathered = data_parallel_predict(lambda b: _predict(spec, state, b, tfi), full, names, torch.device("cpu"), dst=0,
-                                     aliases={"phone": "phoneme"})
+                                     aliases={"phone": "phoneme"}, spec=spec)
     # the same gather with the global frame count stated up front (no agreement round): identical tensors
-    shard = shard_batch(full, rank, world)
+    shard = shard_batch(full, rank, world, spec=spec)
     again = gather_predictions(_predict(spec, state, shard, tfi) if shard is not None else None, names, len(full),
                                torch.device("cpu"), dst=0, aliases={"phone": "phoneme"},
                                frames=S.frame_lengths([int(lengths.max())], spec)[0])
@@ -179,7 +179,7 @@ def _runner_worker(rank, world, port, result_path):
     for step in range(3):
         # the global batch of this step (same on every rank, full-length utterances: equal shards as in the benchmark)
         audio, lengths = synthetic.make_audio(4, 2400, seed=50 + step)
-        shard = shard_batch(Batch(audio, lengths, torch.zeros(4, dtype=torch.long)), rank, world)
+        shard = shard_batch(Batch(audio, lengths, torch.zeros(4, dtype=torch.long)), rank, world, spec=spec)
         steps.append(runner.step(shard))
     steps.append(runner.drain())
     assert steps[0] is None  # the first gather is still in flight when step 0 returns
@@ -291,7 +291,7 @@ def _uneven_runner_worker(rank, world, port, result_path):
         runner = DataParallelRunner(predict, torch.device("cpu"), dst=0, total_utterances=total, outputs=names,
                                     aliases={"phone": "phoneme"})
         audio, lengths = synthetic.make_audio(total, 2400, seed=70 + step, ragged=ragged)
-        shard = shard_batch(Batch(audio, lengths, torch.zeros(total, dtype=torch.long)), rank, world)
+        shard = shard_batch(Batch(audio, lengths, torch.zeros(total, dtype=torch.long)), rank, world, spec=spec)
         if total == 1 and rank == 1:
             assert shard is None
         got = runner.step(shard)
@@ -356,7 +356,7 @@ def _mixed_runner_worker(rank, world, port, result_path):
     delivered = []
     for step, (total, ragged) in enumerate(_MIXED_STEPS):
         audio, lengths = synthetic.make_audio(total, 2400, seed=90 + step, ragged=ragged)
-        shard = shard_batch(Batch(audio, lengths, torch.zeros(total, dtype=torch.long)), rank, world)
+        shard = shard_batch(Batch(audio, lengths, torch.zeros(total, dtype=torch.long)), rank, world, spec=spec)
         delivered.append(runner.step(shard, total_utterances=total))
     delivered.append(runner.drain())
     assert runner.drain() is None  # nothing is handed out twice
@@ -450,9 +450,16 @@ def _variant_worker(rank, world, port, result_path):
     assert padding_sensitive(spec)
     full = Batch(audio, lengths, torch.zeros(len(lengths), dtype=torch.long))
     names = [("syllabic", 4), ("phoneme", 7)]
-    kept = data_parallel_predict(lambda b: _variant_predict(spec, state, b, tfi), full, names, torch.device("cpu"), dst=0,
-                                 keep_length=padding_sensitive(spec))
-    repadded = data_parallel_predict(lambda b: _variant_predict(spec, state, b, tfi), full, names, torch.device("cpu"), dst=0)
+    # the spec decides (round-5 advisor finding: the default used to be "re-pad", silently wrong for these variants) ...
+    kept = data_parallel_predict(lambda b: _variant_predict(spec, state, b, tfi), full, names, torch.device("cpu"), dst=0, spec=spec)
+    # ... an explicit keep_length overrides it, and giving neither is refused
+    repadded = data_parallel_predict(lambda b: _variant_predict(spec, state, b, tfi), full, names, torch.device("cpu"), dst=0,
+                                     keep_length=False)
+    try:
+        shard_batch(full, rank, world)
+        raise AssertionError("shard_batch without spec / keep_length must be refused")
+    except TypeError:
+        pass
     if rank == 0:
         torch.save({"kept": kept.outputs, "repadded": repadded.outputs, "lengths": kept.lengths}, result_path)
     dist.barrier()
@@ -480,3 +487,79 @@ def test_padding_sensitive_variants_shard_with_the_global_length(tmp_path):
         g = got["repadded"][name]
         worst_repadded = max(worst_repadded, ((g - expected[: g.shape[0]]).abs() * valid[: g.shape[0]]).max().item())
     assert worst_repadded > 1e-2  # what the advisor measured: re-padded shards are a different function for these specs
+
+
+# ---- a range report (AMX_ERANGE -> FloatingPointError) on ONE rank must not strand the others in the gather ----
+def _range_report_worker(rank, world, port, result_path):
+    from oracle import allophant_oracle as O
+    from allophant_amd.parallel import DataParallelRunner, RankError
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    spec, state, _, _, tfi = _setup()
+    offsets = synthetic.category_offsets(spec)
+    calls = {"n": 0}
+
+    def predict(batch):
+        # what Estimator.predict does when an EARLIER pass overflowed: it raises before enqueuing anything of this call
+        calls["n"] += 1
+        if rank == 1 and calls["n"] == 2:
+            raise FloatingPointError("an EARLIER forward pass left the range of the planes")
+        out, flen = O.predict(batch.audio_features, batch.lengths, state, spec, tfi, offsets)
+        return _flat_predictions(out, flen)
+
+    names = [("syllabic", 4), ("long", 4), ("phoneme", 7)]
+    log = []
+    # (a) the padded gather of data_parallel_predict: the reporting rank joins the collectives, then raises; rank 0 raises RankError
+    audio, lengths = synthetic.make_audio(4, 2400, seed=21)
+    full = Batch(audio, lengths, torch.zeros(4, dtype=torch.long))
+    ok = data_parallel_predict(predict, full, names, torch.device("cpu"), dst=0, aliases={"phone": "phoneme"}, spec=spec)
+    log.append("first ok" if (ok is not None) == (rank == 0) else "first wrong")
+    try:
+        data_parallel_predict(predict, full, names, torch.device("cpu"), dst=0, aliases={"phone": "phoneme"}, spec=spec)
+        log.append("second returned")
+    except RankError as exc:
+        log.append("RankError " + str(exc)[:20])
+    except FloatingPointError:
+        log.append("FloatingPointError")
+    # (b) the flat, overlapped gather of DataParallelRunner (bench.py --gpus N): the status travels behind the frame lengths
+    calls["n"] = 0
+    runner = DataParallelRunner(predict, torch.device("cpu"), dst=0, verify_shapes=False)
+    statuses = []
+    for step in range(3):
+        shard = shard_batch(full, rank, world, spec=spec)
+        try:
+            got = runner.step(shard)
+            if got is not None:
+                statuses.append(got._status.tolist())
+        except FloatingPointError:
+            statuses.append("raised")
+    try:
+        got = runner.drain()
+        if got is not None:
+            statuses.append(got._status.tolist())
+            got.check_ranks()
+    except FloatingPointError:
+        statuses.append("raised")
+    torch.save({"log": log, "statuses": statuses}, f"{result_path}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_range_report_on_one_rank_does_not_hang_the_gather(tmp_path):
+    """Round-5 advisor finding: ``Estimator.predict`` raises ``FloatingPointError`` for an earlier pass BEFORE the collective, on
+    one rank only -- the others then blocked in the gather forever.  Now the rank joins the step's collectives (its status word
+    travels with the frame lengths) and raises afterwards; the destination raises ``RankError`` (padded gather) or finds the
+    status in the assembled predictions (flat gather, ``Predictions.check_ranks``).  The test finishing at all is the point."""
+    path = str(tmp_path / "range")
+    mp.spawn(_range_report_worker, args=(2, _free_port(), path), nprocs=2, join=True)
+    r0, r1 = torch.load(path + ".0"), torch.load(path + ".1")
+    assert r0["log"][0] == "first ok" and r1["log"][0] == "first ok"
+    assert r0["log"][1].startswith("RankError")       # the destination learns which rank reported
+    assert r1["log"][1] == "FloatingPointError"       # the reporting rank raises its own error -- after the gather
+    # flat gather: step 1 of rank 1 reported; rank 0 sees status [0, 1] for that step and 0 otherwise; rank 1 raised once
+    assert r1["statuses"].count("raised") == 1
+    seen = [s for s in r0["statuses"] if s != "raised"]
+    assert seen.count([0, 1]) == 1 and seen.count([0, 0]) == 2, r0["statuses"]

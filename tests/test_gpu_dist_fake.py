@@ -35,7 +35,7 @@ spec = bench.build_spec()
 est = Estimator(spec, synthetic.make_state_dict(spec, seed=0), "cuda:0", "f16x3")
 tfi = synthetic.make_inventory(spec, 27, seed=0)
 audio, lengths = synthetic.make_audio(32, 160000, seed=1234)
-shard = parallel.shard_batch(Batch(audio, lengths, torch.zeros(32, dtype=torch.long)), rank, world)
+shard = parallel.shard_batch(Batch(audio, lengths, torch.zeros(32, dtype=torch.long)), rank, world, spec=spec)
 n_local = len(shard)
 pred = est.predict(Batch(shard.audio_features.cuda(), shard.lengths, shard.language_ids), tfi)
 fake = C.CDLL(fake_so, mode=C.RTLD_GLOBAL)
@@ -88,7 +88,7 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_process_batch(tmp_path):
     whole_batch = Batch(audio, lengths, torch.zeros(32, dtype=torch.long))
     shard_flat, shard_len = [], []
     for r in range(world):
-        sh = parallel.shard_batch(whole_batch, r, world)
+        sh = parallel.shard_batch(whole_batch, r, world, spec=spec)
         p = est.predict(Batch(sh.audio_features.cuda(), sh.lengths, sh.language_ids), tfi)
         torch.cuda.synchronize()
         shard_flat.append(p._flat.cpu().clone())

@@ -187,7 +187,7 @@ def test_config3_per_gpu_share_against_oracle(amd):
     tfi = synthetic.make_inventory(spec, phones, seed=0)
     audio, lengths = synthetic.make_audio(n, samples, seed=seed)
     whole = amd.Batch(audio, lengths, torch.zeros(n, dtype=torch.long))
-    share = parallel.shard_batch(whole, 0, 8)
+    share = parallel.shard_batch(whole, 0, 8, spec=spec)
     assert len(share) == 4 and torch.equal(share.audio_features, audio[:4])
     est = amd.Estimator(spec, state, "cuda:0", "f16x3")
     pred = est.predict(share.to("cuda:0"), tfi)
