@@ -1480,8 +1480,8 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         for (auto& st : h->steps)
             if (st.time_heads > 0) {
                 cmax = std::max(cmax, st.Cpad);
-                if (time_attention_lds_bytes(T, st.rows / st.time_heads) > 160 * 1024)
-                    return fail(h, AMX_EINVAL, "utterance too long for the time-layer attention (frames + head_dim > 10240)");
+                if (st.rows / st.time_heads > 4096)
+                    return fail(h, AMX_EINVAL, "head_dim of a time-layer classifier beyond 4096");
             }
         if (cmax > 0) {
             WS("tl_x", (size_t)M * cmax * 4, tl_x);
@@ -2073,7 +2073,6 @@ extern "C" int amx_greedy_ctc(amx_handle h, const float* out, const int64_t* fra
     int rc = compute_layout(h, N, L);  // output block geometry is a function of (N, L, inventory) only
     if (rc) return rc;
     const int T = (int)h->layout_T;
-    if ((size_t)T * 4 + 2048 > 64 * 1024) return fail(h, AMX_EINVAL, "utterance too long for the on-device greedy decoder");
     std::vector<int> fl(N);
     for (int n = 0; n < N; ++n) {
         if (frame_lengths[n] < 0 || frame_lengths[n] > T) return fail(h, AMX_EINVAL, "frame length out of range");
@@ -2093,7 +2092,6 @@ extern "C" int amx_greedy_ctc_emissions(int device, const float* emissions, int6
                                         int64_t* tokens, int64_t* timesteps, int32_t* counts, float* scores, void* stream) {
     if (!emissions || !frame_lengths || !tokens || !timesteps || !counts || !scores) return fail(nullptr, AMX_EINVAL, "null buffer");
     if (N < 1 || T < 1 || C < 1) return fail(nullptr, AMX_EINVAL, "empty emission tensor");
-    if ((size_t)T * 4 + 2048 > 64 * 1024) return fail(nullptr, AMX_EINVAL, "utterance too long for the on-device greedy decoder");
     if (hipSetDevice(device) != hipSuccess) return fail(nullptr, AMX_EHIP, "hipSetDevice failed");
     launch_greedy_ctc_emissions(emissions, stride_n, stride_t, frame_lengths, N, (int)T, C, blank_index, tokens, timesteps, counts,
                                 scores, (hipStream_t)stream);

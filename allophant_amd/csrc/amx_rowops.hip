@@ -1147,53 +1147,70 @@ __global__ __launch_bounds__(256) void time_ln_pe_kernel(const float* __restrict
 
 // softmax(q k^T / sqrt(dh) masked to the valid keys of the utterance) v over the frames of one utterance, fp32 on the
 // vector ALU: one wave per (utterance, head, query frame).  Lanes are (key group, d) pairs: DP = pow2 >= min(dh, 64)
-// lanes hold the dh axis, 64 / DP groups stride over the keys.  Scores go through LDS (T floats per wave).
+// lanes hold the dh axis, 64 / DP groups stride over the keys.  Scores go through LDS, `kc` keys at a time (per wave: kc scores,
+// the scaled query and the output accumulator): an utterance with more valid keys than that is walked in chunks with the running
+// maximum / sum of the online softmax, so there is no length limit (nn.MultiheadAttention has none, acoustic_model.py:255-268);
+// up to kc keys -- every utterance below ~ 3 minutes -- the arithmetic is that of the plain two-pass softmax (0 * 0 + x steps).
 // Queries of padded frames are computed like upstream (only keys are masked, nn.MultiheadAttention key_padding_mask).
 template <typename T, int NT>
 __global__ __launch_bounds__(256) void time_attention_kernel(const float* __restrict__ qkv, const int* __restrict__ frame_len,
-                                                             int T_frames, int C, int dh, int dp, T* __restrict__ out,
+                                                             int T_frames, int C, int dh, int dp, int kc, T* __restrict__ out,
                                                              int64_t out_plane, int kpad) {
     extern __shared__ float time_lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = blockIdx.x * 4 + wave, hd = blockIdx.y, n = blockIdx.z;
     if (t >= T_frames) return;
-    float* sc = time_lds + (size_t)wave * (T_frames + dh);
-    float* qs = sc + T_frames;
+    float* sc = time_lds + (size_t)wave * (kc + 2 * dh);
+    float* qs = sc + kc;
+    float* oa = qs + dh;
     const int64_t ld = 3 * (int64_t)C;
     const float* base = qkv + (int64_t)n * T_frames * ld + hd * dh;
     const float scale = 1.0f / sqrtf((float)dh);
-    for (int d = lane; d < dh; d += 64) qs[d] = base[(int64_t)t * ld + d] * scale;
+    for (int d = lane; d < dh; d += 64) {
+        qs[d] = base[(int64_t)t * ld + d] * scale;
+        oa[d] = 0.f;
+    }
     const int len = frame_len[n];
-    float m = -INFINITY;
-    for (int key = lane; key < len; key += 64) {
-        const float* kr = base + (int64_t)key * ld + C;
-        float a = 0.f;
-        for (int d = 0; d < dh; ++d) a = fmaf(qs[d], kr[d], a);
-        sc[key] = a;
-        m = fmaxf(m, a);
-    }
-    m = wave_max(m);
-    float sum = 0.f;
-    for (int key = lane; key < len; key += 64) {
-        float e = expf(sc[key] - m);
-        sc[key] = e;
-        sum += e;
-    }
-    sum = wave_sum(sum);
-    const float inv = 1.0f / sum;
     const int groups = 64 / dp, kg = lane / dp, dl = lane % dp;
+    float m = -INFINITY, l = 0.f;
+    for (int k0 = 0; k0 < len; k0 += kc) {
+        const int nk = len - k0 < kc ? len - k0 : kc;
+        float mc = -INFINITY;
+        for (int key = lane; key < nk; key += 64) {
+            const float* kr = base + (int64_t)(k0 + key) * ld + C;
+            float a = 0.f;
+            for (int d = 0; d < dh; ++d) a = fmaf(qs[d], kr[d], a);
+            sc[key] = a;
+            mc = fmaxf(mc, a);
+        }
+        const float mn = fmaxf(m, wave_max(mc));
+        const float f = expf(m - mn);  // first chunk: exp(-inf) = 0
+        float sum = 0.f;
+        for (int key = lane; key < nk; key += 64) {
+            float e = expf(sc[key] - mn);
+            sc[key] = e;
+            sum += e;
+        }
+        l = l * f + wave_sum(sum);
+        m = mn;
+        for (int d0 = 0; d0 < dh; d0 += dp) {
+            const int d = d0 + dl;
+            float o = 0.f;
+            if (d < dh) {
+                const float* vr = base + (int64_t)k0 * ld + 2 * C + d;
+                for (int key = kg; key < nk; key += groups) o = fmaf(sc[key], vr[(int64_t)key * ld], o);
+            }
+            for (int off = dp; off < 64; off <<= 1) o += __shfl_xor(o, off);
+            if (kg == 0 && d < dh) oa[d] = oa[d] * f + o;
+        }
+    }
+    const float inv = 1.0f / l;
     const int64_t orow = ((int64_t)n * T_frames + t) * kpad;
     for (int d0 = 0; d0 < dh; d0 += dp) {
         const int d = d0 + dl;
-        float o = 0.f;
-        if (d < dh) {
-            const float* vr = base + 2 * C + d;
-            for (int key = kg; key < len; key += groups) o = fmaf(sc[key], vr[(int64_t)key * ld], o);
-        }
-        for (int off = dp; off < 64; off <<= 1) o += __shfl_xor(o, off);
         if (kg == 0 && d < dh) {
             T hi, lo;
-            split16<T, NT>(o * inv, hi, lo);
+            split16<T, NT>(oa[d] * inv, hi, lo);
             T* dst = out + pidx(orow + hd * dh + d, plane_is_il<NT>(out_plane));
             dst[0] = hi;
             if (NT > 1) dst[out_plane] = lo;
@@ -1294,56 +1311,76 @@ __global__ __launch_bounds__(256) void logsoftmax_out_kernel(const OutDesc* __re
 // greedy CTC (reference predictions.py:194-207): argmax, collapse repeats, drop blank 0, 1-based start timesteps,
 // score = sum of the per-frame maxima.  One block per (output, utterance).
 // ----------------------------------------------------------------------------------------------------------------
-// one workgroup decodes one utterance of one output: frame t of the utterance is the C floats at base + t * stride_t
-__device__ __forceinline__ void greedy_ctc_block(const float* __restrict__ base, int64_t stride_t, int C, int len, int T,
+// one workgroup decodes one utterance of one output: frame t of the utterance is the C floats at base + t * stride_t.
+// The argmax indices of CTC_CHUNK frames at a time live in LDS (`chunk` = min(T, CTC_CHUNK) ints); an utterance longer than that is
+// walked chunk by chunk with the last index and the output position carried over, so there is no length limit (the reference's
+// decoder has none, predictions.py:194-207).  A thread adds the maxima of frames tid, tid + 256, ... in ascending order whatever
+// the chunking (CTC_CHUNK % 256 == 0) and the block total is one fixed tree: scores do not depend on T's relation to the chunk.
+constexpr int CTC_CHUNK = 8192;
+__device__ __forceinline__ void greedy_ctc_block(const float* __restrict__ base, int64_t stride_t, int C, int len, int chunk,
                                                  int blank, int64_t* __restrict__ tok, int64_t* __restrict__ ts, int* __restrict__ count,
                                                  float* __restrict__ score_out, unsigned char* smem) {
-    int* idx = (int*)smem;          // [T]
-    int* scan = idx + T;            // [256]
+    int* idx = (int*)smem;          // [chunk]
+    int* scan = idx + chunk;        // [256]
     float* fred = (float*)(scan + 256);  // [256]
     float score = 0.f;
-    for (int t = threadIdx.x; t < len; t += 256) {
-        const float* p = base + (int64_t)t * stride_t;
-        float best = p[0];
-        int bi = 0;
-        for (int c = 1; c < C; ++c) {
-            float v = p[c];
-            if (v > best) { best = v; bi = c; }
+    int pos_base = 0, prev = -1;
+    for (int b = 0; b < len; b += chunk) {
+        const int n = len - b < chunk ? len - b : chunk;
+        for (int t = threadIdx.x; t < n; t += 256) {
+            const float* p = base + (int64_t)(b + t) * stride_t;
+            float best = p[0];
+            int bi = 0;
+            for (int c = 1; c < C; ++c) {
+                float v = p[c];
+                if (v > best) { best = v; bi = c; }
+            }
+            idx[t] = bi;
+            score += best;
         }
-        idx[t] = bi;
-        score += best;
+        __syncthreads();
+        // contiguous segment per thread
+        const int seg = (n + 255) / 256;
+        const int lo = threadIdx.x * seg, hi = lo + seg < n ? lo + seg : n;
+        int cnt = 0;
+        for (int t = lo; t < hi; ++t) {
+            const bool start = b + t == 0 || idx[t] != (t > 0 ? idx[t - 1] : prev);
+            cnt += (start && idx[t] != blank) ? 1 : 0;
+        }
+        scan[threadIdx.x] = cnt;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            int v = threadIdx.x >= off ? scan[threadIdx.x - off] : 0;
+            __syncthreads();
+            scan[threadIdx.x] += v;
+            __syncthreads();
+        }
+        int pos = pos_base + scan[threadIdx.x] - cnt;  // exclusive prefix
+        for (int t = lo; t < hi; ++t) {
+            const bool start = b + t == 0 || idx[t] != (t > 0 ? idx[t - 1] : prev);
+            if (start && idx[t] != blank) {
+                tok[pos] = idx[t];
+                ts[pos] = b + t + 1;
+                ++pos;
+            }
+        }
+        const int total = scan[255], last = idx[n - 1];
+        __syncthreads();  // every thread has read idx / scan of this chunk before the next one overwrites them
+        pos_base += total;
+        prev = last;
     }
     fred[threadIdx.x] = score;
     __syncthreads();
-    // contiguous segment per thread
-    const int seg = (len + 255) / 256;
-    const int lo = threadIdx.x * seg, hi = lo + seg < len ? lo + seg : len;
-    int cnt = 0;
-    for (int t = lo; t < hi; ++t) {
-        bool start = t == 0 || idx[t] != idx[t - 1];
-        cnt += (start && idx[t] != blank) ? 1 : 0;
-    }
-    scan[threadIdx.x] = cnt;
-    __syncthreads();
     for (int off = 1; off < 256; off <<= 1) {
-        int v = threadIdx.x >= off ? scan[threadIdx.x - off] : 0;
         float f = threadIdx.x + off < 256 ? fred[threadIdx.x + off] : 0.f;
         __syncthreads();
-        scan[threadIdx.x] += v;
         if ((threadIdx.x & (2 * off - 1)) == 0) fred[threadIdx.x] += f;
         __syncthreads();
     }
-    int pos = scan[threadIdx.x] - cnt;  // exclusive prefix
-    for (int t = lo; t < hi; ++t) {
-        bool start = t == 0 || idx[t] != idx[t - 1];
-        if (start && idx[t] != blank) {
-            tok[pos] = idx[t];
-            ts[pos] = t + 1;
-            ++pos;
-        }
+    if (threadIdx.x == 0) {
+        *count = pos_base;
+        *score_out = fred[0];
     }
-    if (threadIdx.x == 255) *count = scan[255];
-    if (threadIdx.x == 0) *score_out = fred[0];
 }
 
 __global__ __launch_bounds__(256) void greedy_ctc_kernel(const OutDesc* __restrict__ descs, const float* __restrict__ out,
@@ -1355,7 +1392,7 @@ __global__ __launch_bounds__(256) void greedy_ctc_kernel(const OutDesc* __restri
     const OutDesc d = descs[o];
     const int len = frame_len[n] < T ? frame_len[n] : T;
     const float* base = out + (int64_t)T * N * d.prefix + (int64_t)n * d.C;
-    greedy_ctc_block(base, (int64_t)N * d.C, d.C, len, T, 0, tokens + ((int64_t)o * N + n) * T, timesteps + ((int64_t)o * N + n) * T,
+    greedy_ctc_block(base, (int64_t)N * d.C, d.C, len, T < CTC_CHUNK ? T : CTC_CHUNK, 0, tokens + ((int64_t)o * N + n) * T, timesteps + ((int64_t)o * N + n) * T,
                      counts + o * N + n, scores + o * N + n, smem);
 }
 
@@ -1368,7 +1405,7 @@ __global__ __launch_bounds__(256) void greedy_ctc_emissions_kernel(const float* 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int n = blockIdx.x;
     const int len = frame_len[n] < T ? frame_len[n] : T;
-    greedy_ctc_block(emissions + (int64_t)n * stride_n, stride_t, C, len < 0 ? 0 : len, T, blank, tokens + (int64_t)n * T,
+    greedy_ctc_block(emissions + (int64_t)n * stride_n, stride_t, C, len < 0 ? 0 : len, T < CTC_CHUNK ? T : CTC_CHUNK, blank, tokens + (int64_t)n * T,
                      timesteps + (int64_t)n * T, counts + n, scores + n, smem);
 }
 
@@ -1663,7 +1700,12 @@ void launch_time_ln_pe(int prec, const float* x, int64_t M, int C, int T, const 
                                           pe_base, (T16*)out, out_plane, kpad));
 }
 
-size_t time_attention_lds_bytes(int T, int dh) { return (size_t)4 * (T + dh) * sizeof(float); }
+// keys per chunk of the time-layer attention: the whole utterance when 4 waves x (T + 2 dh) floats fit the 160 KiB of a CU
+static int time_attention_chunk(int T, int dh) {
+    const int room = 160 * 1024 / 16 - 2 * dh;
+    return T < room ? T : room;
+}
+size_t time_attention_lds_bytes(int T, int dh) { return (size_t)4 * (time_attention_chunk(T, dh) + 2 * dh) * sizeof(float); }
 
 template <typename T, int NT>
 static void time_attention_launch(const float* qkv, const int* frame_len, int N, int T_frames, int C, int heads, void* out,
@@ -1675,7 +1717,7 @@ static void time_attention_launch(const float* qkv, const int* frame_len, int N,
     auto kernel = time_attention_kernel<T, NT>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kernel, dim3((unsigned)((T_frames + 3) / 4), heads, N), dim3(256), lds, s, qkv, frame_len, T_frames, C,
-                       dh, dp, (T*)out, out_plane, kpad);
+                       dh, dp, time_attention_chunk(T_frames, dh), (T*)out, out_plane, kpad);
 }
 
 void launch_time_attention(int prec, const float* qkv, const int* frame_len, int N, int T, int C, int heads, void* out,
@@ -1692,14 +1734,14 @@ void launch_logsoftmax_out(const OutDesc* descs_dev, int n_out, const float* log
 
 void launch_greedy_ctc(const OutDesc* descs_dev, int n_out, const float* out, const int* frame_len, int N, int T,
                        int64_t* tokens, int64_t* timesteps, int* counts, float* scores, hipStream_t s) {
-    size_t lds = (size_t)T * sizeof(int) + 256 * sizeof(int) + 256 * sizeof(float);
+    size_t lds = (size_t)(T < CTC_CHUNK ? T : CTC_CHUNK) * sizeof(int) + 256 * sizeof(int) + 256 * sizeof(float);
     hipLaunchKernelGGL(greedy_ctc_kernel, dim3(N, n_out), dim3(256), lds, s, descs_dev, out, frame_len, N, T, tokens,
                        timesteps, counts, scores);
 }
 
 void launch_greedy_ctc_emissions(const float* emissions, int64_t stride_n, int64_t stride_t, const int* frame_len, int N, int T,
                                  int C, int blank, int64_t* tokens, int64_t* timesteps, int* counts, float* scores, hipStream_t s) {
-    size_t lds = (size_t)T * sizeof(int) + 256 * sizeof(int) + 256 * sizeof(float);
+    size_t lds = (size_t)(T < CTC_CHUNK ? T : CTC_CHUNK) * sizeof(int) + 256 * sizeof(int) + 256 * sizeof(float);
     hipLaunchKernelGGL(greedy_ctc_emissions_kernel, dim3(N), dim3(256), lds, s, emissions, stride_n, stride_t, frame_len, T, C,
                        blank, tokens, timesteps, counts, scores);
 }
