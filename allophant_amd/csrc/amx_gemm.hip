@@ -169,8 +169,28 @@ void launch_fixup(const GemmParams& p, int splits, hipStream_t stream) {
                        (int64_t)p.M * p.N);
 }
 
+// LayerNorm fold (GemmParams.row_coef / ln_partial; callers checked gemm_ln_fold_ok): its own kernel instances, one piece, no K chunks
+template <typename T, int NT, int MI, int NI, int FOLD>
+void launch_pp_fold(const GemmParams& p, hipStream_t stream) {
+    static OncePerDevice attr;
+    constexpr int lds = pp::lds_bytes(NT, MI, NI);
+    if (attr.first())
+        (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<T, NT, MI, NI, FOLD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const int tiles = ((p.N + NI * 64 - 1) / (NI * 64)) * ((p.M + MI * 32 - 1) / (MI * 32));
+    const int cus = device_cus();
+    hipLaunchKernelGGL((gemm_pp_kernel<T, NT, MI, NI, FOLD>), dim3(tiles < cus ? tiles : cus, 1, 1), dim3(512), lds, stream, p);
+}
+
 template <typename T, int NT, int MI, int NI = 4>
 void launch_pp_tiles(const GemmParams& p, int splits, hipStream_t stream) {
+    if (p.ln_partial) {
+        if constexpr (NI == 4) launch_pp_fold<T, NT, MI, 4, 2>(p, stream);
+        return;
+    }
+    if (p.row_coef) {
+        launch_pp_fold<T, NT, MI, NI, 1>(p, stream);
+        return;
+    }
     static OncePerDevice attr;
     constexpr int lds = pp::lds_bytes(NT, MI, NI);
     if (attr.first())
