@@ -1417,7 +1417,10 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     // Ragged batch: the conv stack skips what lies wholly in an utterance's padding (conv0: frame blocks; the row-complete
     // layers 1..n-2: 128-row tiles).  A valid frame of any layer only reads valid frames of the layer below, and the rows
     // left unwritten (stale, possibly non-finite) stay inside padded rows until the feature projection zeroes those.
-    const bool ragged = Mp < M && !keep && !no_pack_env && !(flags & AMX_FLAG_NO_PACK);
+    // (only from a tenth of padding on -- the threshold of the packed rows: below it the padded frames are simply computed, and
+    // NOTHING of the pass depends on the lengths by value any more -- lengths, frame counts and masks are device buffers the plan
+    // refreshes -- so a recording of this (N, L) geometry serves every batch of that geometry: see the key below)
+    const bool ragged = Mp < M && Mp * 10 <= M * 9 && !keep && !no_pack_env && !(flags & AMX_FLAG_NO_PACK);
     // per conv layer i >= 1: the ascending list of its 128-row output tiles that hold a row some utterance owns
     int* d_tiles = nullptr;
     size_t tile_first[AMX_MAX_CONV + 1] = {0};
@@ -1939,8 +1942,14 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         key.reserve(10 + (size_t)N);
         key.insert(key.end(), {(int64_t)(intptr_t)d_audio, (int64_t)(intptr_t)d_out, (int64_t)N, L, (int64_t)flags, (int64_t)needs_qkv_zero,
                                (int64_t)h->inv, (int64_t)h->inventories[h->inv].generation, (int64_t)h->ws_gen});
-        key.insert(key.end(), lengths, lengths + N);
-        if (!h->graphs.empty() && h->graphs.front().key.size() >= 9 && h->graphs.front().key[8] != (int64_t)h->ws_gen) {
+        // A recording is keyed on GEOMETRY where it can be (ABI 6): in the padded layout without tile skipping every kernel reads
+        // lengths / frame counts / masks from the device buffers the plan region has just refreshed (no length travels by value in a
+        // kernel node), so batches of one (N, L) with different lengths -- the reference's loop feeds a new batch every iteration,
+        // run.py:742-753 -- replay one recording.  Packed rows and skipped conv tiles size grids and tile lists by the lengths:
+        // those passes keep them in the key.
+        key.push_back(packed ? 2 : (ragged ? 1 : 0));
+        if (packed || ragged) key.insert(key.end(), lengths, lengths + N);
+        if (!h->graphs.empty() && h->graphs.front().key.size() >= 10 && h->graphs.front().key[8] != (int64_t)h->ws_gen) {
             // a workspace buffer moved since these were recorded (ws_get synchronised the device before freeing it)
             drop_graphs(h);
         }
@@ -1983,6 +1992,13 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
                     entry.key = key;
                     entry.exec = exec;
                     entry.graph = graph;
+                    // AMX_GRAPH_DROP_TEMPLATE=1 (developer switch, tools/r06_graph_fault.sh): the round-5 code before its fix --
+                    // the template destroyed right after instantiation, only the executable kept
+                    static const bool drop_template = dev_switch("AMX_GRAPH_DROP_TEMPLATE");
+                    if (drop_template) {
+                        (void)hipGraphDestroy(graph);
+                        entry.graph = nullptr;
+                    }
                     entry.last_use = ++h->graph_clock;
                     h->graphs.push_back(std::move(entry));
                     ++h->graph_captures;

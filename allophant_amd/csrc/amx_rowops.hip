@@ -1805,8 +1805,20 @@ __global__ __launch_bounds__(256) void zero_fill_2d_kernel(unsigned char* __rest
 }
 }  // namespace
 
+// Developer switches that put the round-5 replay fault back (tools/r06_graph_fault.sh: which of the two changes removed it?):
+// AMX_GRAPH_MEMSET_NODES=1 -- zero fills and device copies of a pass as hipMemsetAsync / hipMemcpyAsync again, i.e. memset / memcpy
+// NODES in a recording.  (Constants in the product build: amx_common.h dev_switch.)
+static bool graph_memset_nodes() {
+    static const bool on = dev_switch("AMX_GRAPH_MEMSET_NODES");
+    return on;
+}
+
 void launch_zero(void* p, size_t bytes, hipStream_t s) {
     if (bytes == 0) return;
+    if (graph_memset_nodes()) {
+        (void)hipMemsetAsync(p, 0, bytes, s);
+        return;
+    }
     const size_t words = bytes / 4;
     size_t blocks = (words / 4 + 255) / 256 + 1;
     if (blocks > 4096) blocks = 4096;
@@ -1816,6 +1828,10 @@ void launch_zero(void* p, size_t bytes, hipStream_t s) {
 // device-to-device copy of a pass as a kernel, for the same reason (bytes a multiple of 4)
 void launch_copy(void* dst, const void* src, size_t bytes, hipStream_t s) {
     if (bytes == 0) return;
+    if (graph_memset_nodes()) {
+        (void)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s);
+        return;
+    }
     const size_t words = bytes / 4;
     size_t blocks = (words / 4 + 255) / 256 + 1;
     if (blocks > 8192) blocks = 8192;
@@ -1824,6 +1840,10 @@ void launch_copy(void* dst, const void* src, size_t bytes, hipStream_t s) {
 
 void launch_zero_2d(void* base, size_t pitch, size_t width_bytes, size_t rows, hipStream_t s) {
     if (width_bytes == 0 || rows == 0) return;
+    if (graph_memset_nodes()) {
+        (void)hipMemset2DAsync(base, pitch, 0, width_bytes, rows, s);
+        return;
+    }
     const size_t words = width_bytes / 4;
     size_t bx = (words + 255) / 256;
     if (bx > 64) bx = 64;

@@ -173,3 +173,61 @@ def test_replays_between_eager_bursts_stay_clean(amd, model):
             est.synchronize()
     captured, replayed = est.graph_info()
     assert replayed >= 40
+
+
+def test_one_recording_serves_every_batch_of_its_geometry(amd, model):
+    """ABI 6 (round-5 review, item 6): in the padded layout nothing of a pass depends on the utterance lengths by value -- they are
+    device buffers the plan refreshes in front of the launch -- so the recording of an (N, L) geometry is replayed for OTHER
+    lengths at that geometry (the reference's loop feeds a new batch every iteration, run.py:742-753).  Each batch's replayed
+    output is bitwise its own eager pass; a batch ragged enough for packed rows (grids sized by the lengths) still gets a pass
+    of its own."""
+    spec, est = model
+    tfi = synthetic.make_inventory(spec, 27, seed=0)
+    n, samples = 4, 160000
+    audio, full = synthetic.make_audio(n, samples, seed=31)
+    variants = [full.clone()]
+    for shave in ([0, 8000, 2000, 10000], [0, 320, 12000, 4000], [0, 0, 0, 15000]):
+        variants.append(full - torch.tensor(shave))
+    # (buffer addresses are part of a recording: the loop below reuses one device audio buffer and one output buffer, as a
+    # prefetcher with a ring of device buffers does)
+    dev_audio = torch.empty(n, samples, dtype=torch.float32, device="cuda")
+    host_audio, wants = [], []
+    for lengths in variants:
+        a = audio.clone()
+        for i in range(n):
+            a[i, int(lengths[i]):] = 0
+        dev_audio.copy_(a)
+        eager = est.predict(amd.Batch(dev_audio, lengths, torch.zeros(n, dtype=torch.long)), tfi, True, _no_graph=True)
+        torch.cuda.synchronize()
+        assert est.pass_info()["packed"] == 0 and est.pass_info()["graph"] == 0
+        host_audio.append(a)
+        wants.append((eager._flat.clone(), eager.lengths.cpu().clone()))
+    buf = torch.empty(wants[0][0].numel(), dtype=torch.float32, device="cuda")
+    c0, r0 = est.graph_info()
+    order = [0, 0, 0, 1, 2, 3, 1, 0, 3, 2]
+    modes = []
+    for b in order:
+        buf.fill_(float("nan"))
+        dev_audio.copy_(host_audio[b])
+        pred = est.predict(amd.Batch(dev_audio, variants[b], torch.zeros(n, dtype=torch.long)), tfi, True, _out=buf)
+        torch.cuda.synchronize()
+        modes.append(est.pass_info()["graph"])
+        assert torch.equal(pred.lengths.cpu(), wants[b][1]), b
+        assert torch.equal(pred._flat, wants[b][0]), f"batch {b} replayed through the geometry's recording differs from its eager pass"
+    c1, r1 = est.graph_info()
+    assert c1 - c0 == 1, (c1 - c0, modes)                     # ONE recording for the four sets of lengths
+    assert modes[3:] == [2] * 7, modes                        # every later batch, whatever its lengths, is a replay
+    # a batch ragged enough to run on packed rows is keyed on its lengths as before
+    ragged = full - torch.tensor([0, 60000, 70000, 50000])
+    a = audio.clone()
+    for i in range(n):
+        a[i, int(ragged[i]):] = 0
+    rb = amd.Batch(a.cuda(), ragged, torch.zeros(n, dtype=torch.long))
+    eager = est.predict(rb, tfi, True, _no_graph=True)
+    torch.cuda.synchronize()
+    assert est.pass_info()["packed"] > 0
+    for _ in range(3):
+        pred = est.predict(rb, tfi, True)
+        torch.cuda.synchronize()
+        valid = (torch.arange(pred.outputs["phoneme"].shape[0]).unsqueeze(1) < pred.lengths.cpu().unsqueeze(0)).unsqueeze(-1).cuda()
+        assert torch.equal(pred.outputs["phoneme"] * valid, eager.outputs["phoneme"] * valid)
