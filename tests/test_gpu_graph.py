@@ -65,8 +65,10 @@ def test_graph_replay_is_bitwise_the_eager_pass_padded(amd, model, n, seconds):
     audio, lengths = synthetic.make_audio(n, seconds * 16000, seed=1234)
     batch = amd.Batch(audio.cuda(), lengths, torch.zeros(n, dtype=torch.long))
     captured, replayed = _eager_then_graph(amd, est, batch, tfi)
-    # pass 0 re-zeroes Q / K / V for the new geometry (its own key), pass 1 is the first of the steady key, pass 2 records
-    assert captured == 1 and replayed >= 2, (captured, replayed)
+    # pass 0 re-zeroes Q / K / V for the new geometry (its own key), pass 1 is the first of the steady key, pass 2 records -- unless
+    # an earlier test of this module left a recording of the same geometry on the same buffer addresses (recordings are keyed on
+    # geometry since ABI 6: the caching allocator hands the same blocks out again), which is then simply replayed
+    assert (captured == 1 and replayed >= 2) or (captured == 0 and replayed >= 4), (captured, replayed)
 
 
 @pytest.mark.parametrize("n,seconds", [(4, 10), (32, 10)])
