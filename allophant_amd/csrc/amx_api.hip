@@ -429,8 +429,8 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
     *out = nullptr;
     if (cfg->abi_version != AMX_ABI_VERSION) return fail(nullptr, AMX_EINVAL, "ABI version mismatch");
     if (cfg->n_conv < 2 || cfg->n_conv > AMX_MAX_CONV) return fail(nullptr, AMX_EINVAL, "n_conv out of range");
-    if (cfg->hidden % cfg->heads != 0 || cfg->hidden / cfg->heads != 64)
-        return fail(nullptr, AMX_EINVAL, "head_dim must be 64 (hidden / heads)");
+    if (cfg->heads < 1 || cfg->hidden % cfg->heads != 0 || (cfg->hidden / cfg->heads) % 8 || cfg->hidden / cfg->heads > 128)
+        return fail(nullptr, AMX_EINVAL, "head_dim (hidden / heads) must be a multiple of 8 and at most 128");
     if (cfg->hidden > 1024 || cfg->hidden % 8 || cfg->conv_dim > 1024 || cfg->conv_dim % 8)
         return fail(nullptr, AMX_EINVAL, "hidden and conv_dim must be multiples of 8 and <= 1024");
     if (cfg->conv_dim >= 64 && cfg->conv_dim % 64) return fail(nullptr, AMX_EINVAL, "conv_dim must be < 64 or a multiple of 64");
@@ -643,7 +643,7 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
     // ---- encoder layers ----
     h->layers.resize(cfg->layers);
     // folded into W_q / b_q: dh^-0.5 and log2(e) -- the attention softmax runs in base 2 (v_exp_f32)
-    const float qscale = 1.44269504088896340736f / sqrtf(64.0f);
+    const float qscale = 1.44269504088896340736f / sqrtf((float)(D / cfg->heads));
     for (int l = 0; l < cfg->layers; ++l) {
         Layer& ly = h->layers[l];
         std::string p = AM + "encoder.layers." + std::to_string(l) + ".";
@@ -1085,7 +1085,7 @@ static int64_t max_utterances_for(const amx_config& c, int NT, int64_t L) {
     // conv activations [N * Ts[i], C]: plane + one utterance (tiles crossing an utterance boundary)
     for (int i = 1; i < c.n_conv; ++i) best = std::min(best, LIMIT / (Ts[i] * C * 2) - 1);
     best = std::min(best, LIMIT / (T * wide * 2));        // FFN activation / fused QKV rows
-    best = std::min(best, LIMIT / (H * Tp * 64 * 2));     // Q / K / V planes
+    best = std::min(best, LIMIT / (H * Tp * (D / H > 64 ? 128 : 64) * 2));     // Q / K / V planes (rows padded to 64 / 128 columns)
     best = std::min(best, LIMIT / ((T + c.pos_kernel) * D * 2));  // padded image of the positional convolution
     return std::max<int64_t>(best, 0);
 }
@@ -1349,7 +1349,10 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     WS("h", (size_t)M * D * 4, hbuf);
     WS("xp", (size_t)M * D * 2 * NT + PLANE_SLACK, xp);
     WS("hg", (size_t)N * Tpad * D * 2 * NT, hg);
-    const size_t qkv_bytes = (size_t)N * H * Tp * 64 * 2 * NT;
+    // head dimension and the width of a Q / K / V row: 64 columns, 128 for heads wider than that (the columns beyond dh stay zero:
+    // the buffers are zero-filled when they are created and the QKV scatter writes the dh real columns only)
+    const int dh = D / H, dhp = dh > 64 ? 128 : 64;
+    const size_t qkv_bytes = (size_t)N * H * Tp * dhp * 2 * NT;
     if ((rc = ws_get(h, "q", qkv_bytes, &qb, true))) return rc;
     if ((rc = ws_get(h, "k", qkv_bytes, &kb, true))) return rc;
     if ((rc = ws_get(h, "vt", qkv_bytes, &vtb, true))) return rc;
@@ -1523,7 +1526,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     // ---- the encoder layers' products (plan: the enqueue region only launches them) ----
     const int64_t Mrows = packed ? Mp : M;  // rows the layers work on
     const int64_t xp_plane = pln(h, Mrows * D);
-    const int64_t qk_plane = packed ? (int64_t)H * TpTot * 64 : (int64_t)N * H * Tp * 64;
+    const int64_t qk_plane = packed ? (int64_t)H * TpTot * dhp : (int64_t)N * H * Tp * dhp;
     float* const stream = (float*)(packed ? hpk : hbuf);  // the residual stream of the layers [Mrows, D]
     auto with_ws = [&](GemmParams g) {
         g.splitk_ws = (float*)splitk;
@@ -1539,7 +1542,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         g.mode = 1; g.q = qb; g.k = kb; g.v = vtb;
         g.qk_plane = qk_plane;
         // packed rows: one "utterance" of Mp rows, so the scatter writes row m of head hh to [hh][m][:]
-        g.T = packed ? (int)std::max<int64_t>(Mp, 8) : T; g.Tp = packed ? TpTot : Tp; g.H = H; g.dh = 64;
+        g.T = packed ? (int)std::max<int64_t>(Mp, 8) : T; g.Tp = packed ? TpTot : Tp; g.H = H; g.dh = dh; g.dhp = dhp;
         return with_ws(g);
     };
     auto oproj_params = [&](const Layer& ly) {
@@ -1615,7 +1618,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     }
     if (packed) {
         // rows [Mp, TpTot) of every head are read (never used) by the last key tile and query block: keep them finite
-        const size_t row_b = 64 * 2, tail = (size_t)(TpTot - Mp) * row_b, pitch = (size_t)TpTot * row_b;
+        const size_t row_b = (size_t)dhp * 2, tail = (size_t)(TpTot - Mp) * row_b, pitch = (size_t)TpTot * row_b;
         for (void* buf : {qb, kb, vtb})  // the planes lie back to back: NT * H blocks of TpTot rows
             launch_zero_2d((char*)buf + (size_t)Mp * row_b, pitch, tail, (size_t)NT * H, s);
     }
@@ -1834,7 +1837,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             a.qk_plane = qk_plane;
             a.out = ao; a.out_plane = xp_plane;
             a.frame_len = d_frames_enc;
-            a.N = N; a.H = H; a.T = T; a.Tp = packed ? TpTot : Tp; a.dh = 64;
+            a.N = N; a.H = H; a.T = T; a.Tp = packed ? TpTot : Tp; a.dh = dh; a.dhp = dhp;
             a.row_off = packed ? (const int*)d_rowoff : nullptr;
             a.order = packed ? (const int*)d_rowoff + N + 1 : nullptr;
             { Timed t_(h, AMX_KC_ATTENTION); launch_attention(prec, a, s); }

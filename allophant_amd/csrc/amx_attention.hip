@@ -1,4 +1,5 @@
-// Flash-style multi-head self-attention with key-padding mask for gfx950 (head_dim 64), never materialising T x T.
+// Flash-style multi-head self-attention with key-padding mask for gfx950 (head_dim 64; other head dimensions up to 128 on a wider
+// instance of the first kernel: NDH), never materialising T x T.
 //
 // Per workgroup: one (utterance, head) and WAVES x 32 queries.  Q, K and V arrive row-major [N, H, Tp, 64] as 16-bit
 // planes from the QKV projection epilogue; Q already carries dh^-0.5 * log2(e), so the softmax runs on v_exp_f32
@@ -78,7 +79,7 @@ __device__ __forceinline__ typename Vec2<T>::type residual2(f32x2 x, typename Ve
 // waves per SIMD the register allocation must allow: two 8-wave workgroups or four 4-wave / 32-key workgroups per CU -> 4;
 // two 4-wave / 64-key workgroups -> 2
 #ifndef AMX_ATTN_OCC
-#define AMX_ATTN_OCC ((KS == 1 && (WAVES == 8 || KT == 32)) ? 4 : 2)
+#define AMX_ATTN_OCC ((NDH == 1 && KS == 1 && (WAVES == 8 || KT == 32)) ? 4 : 2)
 #endif
 // KT = keys per tile (64; a 32-key instance with four 4-wave workgroups per CU was 5 % slower at 32 x 10 s)
 // PACKED: the packed-row layout of a ragged batch (AttnParams.row_off), a compile-time variant so that the padded kernel
@@ -94,9 +95,19 @@ __device__ __forceinline__ typename Vec2<T>::type residual2(f32x2 x, typename Ve
 // pieces: 512 partial-line write requests for 8 KiB.  The patch (the idle K / V ring behind the last tile barrier; 32 rows x 256
 // bytes per wave, 16-byte chunks XOR-swizzled by the row) is read back row-major: 8 stores of 16 bytes per lane, whole 128-byte
 // lines.  Same values, same addresses: bitwise the direct form.
-template <typename T, int NT, int WAVES, int KT, bool PACKED, int KS = 1, bool TSTORE = true>
+// NDH (round 6): head dimensions other than 64.  Q / K / V rows are DHP = 64 NDH elements wide -- AttnParams.dh valid columns, the
+// rest zero (the QKV scatter never writes them, the buffers are zero-filled): the zero columns add nothing to Q.K^T, and the
+// columns of O beyond dh are simply not stored.  NDH = 1 serves dh <= 64, NDH = 2 dh in (64, 128] (XLS-R 1B / 2B: 80 / 120): a K / V
+// tile is then two [KT x 64] sub-tiles side by side in LDS, each in the layout of the dh = 64 kernel (same swizzles, same fragment
+// addresses), the score chain runs over both and O holds four 32-column blocks -- 64 more fragment and 32 more accumulator
+// registers, hence two waves per SIMD.  dh != 64 stores through the masked direct path (TSTORE's line patches assume 64 columns).
+template <typename T, int NT, int WAVES, int KT, bool PACKED, int KS = 1, bool TSTORE = true, int NDH = 1>
 __global__ __launch_bounds__(WAVES * KS * 64, AMX_ATTN_OCC) void attn_kernel(const AttnParams p) {
-    constexpr int TILE = KT * 128;     // bytes of one K or V tile of one plane
+    static_assert(NDH == 1 || (KS == 1 && !TSTORE), "the wide form has neither the key split nor the line-patch stores");
+    constexpr int DHP = 64 * NDH;      // padded head dimension = elements per Q / K / V row
+    constexpr int ROWB = DHP * 2;      // bytes per row of one plane
+    constexpr int SUB = KT * 128;      // bytes of one [KT x 64] sub-tile of one plane
+    constexpr int TILE = SUB * NDH;    // bytes of one K or V tile of one plane
     constexpr int NC = KT / 32;        // 32-key blocks per tile
     typedef typename Vec8<T>::type V8;
     typedef typename Vec4<T>::type V4;
@@ -140,7 +151,7 @@ __global__ __launch_bounds__(WAVES * KS * 64, AMX_ATTN_OCC) void attn_kernel(con
     constexpr bool packed = PACKED;
     const int roff = packed ? p.row_off[n] : 0;
     if (packed && qblock * QB >= klen) return;
-    const int64_t first = packed ? ((int64_t)h * p.Tp + roff) * DH : (int64_t)nh * p.Tp * DH;  // element offset of row 0
+    const int64_t first = packed ? ((int64_t)h * p.Tp + roff) * DHP : (int64_t)nh * p.Tp * DHP;  // element offset of row 0
     const int q_rows = packed ? p.Tp - roff : p.Tp;  // rows that may be read from `first` on
 
     const T* Qb = (const T*)p.q + first;
@@ -148,31 +159,34 @@ __global__ __launch_bounds__(WAVES * KS * 64, AMX_ATTN_OCC) void attn_kernel(con
     const uint32_t plane_b = (uint32_t)(p.qk_plane * 2);
 
     // Q fragments (B operand): lane (query, hh) holds Q[query][16ks + 8hh + j]
-    V8 qf[NT][4];
+    V8 qf[NT][4 * NDH];
     {
         const int qr = query < q_rows ? query : q_rows - 1;
 #pragma unroll
         for (int pl = 0; pl < NT; ++pl)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                qf[pl][ks] = *(const V8*)(Qb + (int64_t)pl * p.qk_plane + (int64_t)qr * DH + ks * 16 + 8 * hh);
+            for (int ks = 0; ks < 4 * NDH; ++ks)
+                qf[pl][ks] = *(const V8*)(Qb + (int64_t)pl * p.qk_plane + (int64_t)qr * DHP + ks * 16 + 8 * hh);
     }
 
     // ---- DMA: this wave moves pieces wave, wave + WAVES, ... (8 rows x 128 B) of every K and V tile plane ----
     // piece parity == wave parity (WAVES is even), so the swizzled source chunk is a per-lane constant
-    const uint32_t voff_k = (uint32_t)((lane >> 3) * 128 + (((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) << 4));
-    const uint32_t voff_v = (uint32_t)((lane >> 3) * 128 + (((lane & 7) ^ (4 * ((lane >> 4) & 1))) << 4));
+    // (a piece is 8 rows x 128 B of ONE sub-tile: its rows are ROWB bytes apart in memory, its 128 bytes at dhh * 128 into the row)
+    const uint32_t voff_k = (uint32_t)((lane >> 3) * ROWB + (((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) << 4));
+    const uint32_t voff_v = (uint32_t)((lane >> 3) * ROWB + (((lane & 7) ^ (4 * ((lane >> 4) & 1))) << 4));
     auto stage = [&](int kt, int st) {
 #pragma unroll
         for (int pl = 0; pl < NT; ++pl)
 #pragma unroll
-            for (int j = 0; j < PPW; ++j) {
-                const int piece = wave + WAVES * j;
-                const uint32_t so = (uint32_t)kt * TILE + pl * plane_b + piece * 1024;
-                unsigned char* dst = ring + st * STAGE + pl * 2 * TILE + piece * 1024;
-                dma16(k_rsrc, dst, voff_k, so);  // (inline asm, not the builtin: amx_common.h)
-                dma16(v_rsrc, dst + TILE, voff_v, so);
-            }
+            for (int dhh = 0; dhh < NDH; ++dhh)
+#pragma unroll
+                for (int j = 0; j < PPW; ++j) {
+                    const int piece = wave + WAVES * j;
+                    const uint32_t so = (uint32_t)kt * (KT * ROWB) + pl * plane_b + piece * (8 * ROWB) + dhh * 128;
+                    unsigned char* dst = ring + st * STAGE + pl * 2 * TILE + dhh * SUB + piece * 1024;
+                    dma16(k_rsrc, dst, voff_k, so);  // (inline asm, not the builtin: amx_common.h)
+                    dma16(v_rsrc, dst + TILE, voff_v, so);
+                }
     };
 
     // ---- LDS read addresses ----
@@ -189,9 +203,11 @@ __global__ __launch_bounds__(WAVES * KS * 64, AMX_ATTN_OCC) void attn_kernel(con
             vaddr[dt] = TILE + (4 * hh + q4) * 128 + 64 * (dt ^ ((q4 >> 1) & 1)) + 32 * ((lane >> 4) & 1) + 8 * pp;
     }
 
-    f32x16 O[2];
+    f32x16 O[2 * NDH];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { O[0][r] = 0.f; O[1][r] = 0.f; }
+    for (int b = 0; b < 2 * NDH; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[b][r] = 0.f;
     float m_run = 0.f, l_run = 0.f;  // scores are kept relative to m_run; the first tile sets it
 
     if (my_tiles > 0) stage(kt0, 0);
@@ -203,7 +219,7 @@ __global__ __launch_bounds__(WAVES * KS * 64, AMX_ATTN_OCC) void attn_kernel(con
 #pragma unroll
     for (int pl = 0; pl < NT; ++pl)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(qf[pl][ks]));
+        for (int ks = 0; ks < 4 * NDH; ++ks) asm volatile("" ::"v"(qf[pl][ks]));
 
 #ifdef AMX_ATTN_STAMP
     // developer diagnostic (tools/attn_bench.hip): cycles per phase of a key tile, summed in scalar registers
@@ -241,24 +257,25 @@ __global__ __launch_bounds__(WAVES * KS * 64, AMX_ATTN_OCC) void attn_kernel(con
 #pragma unroll
             for (int r = 0; r < 16; ++r) X[c][r] = neg_m;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
+            for (int kq = 0; kq < 4 * NDH; ++kq) {
+                const int ks = kq & 3, dsub = (kq >> 2) * SUB;  // K step inside its [KT x 64] sub-tile
 #ifdef AMX_ATTN_ABL_NOLDS  // developer ablation (wrong results): one K fragment read per tile instead of 16
                 const V8 kf = *(const V8*)(sb + kaddr0);
                 if (NT > 1) {
                     const V8 kl = *(const V8*)(sb + 2 * TILE + kaddr0);
 #else
-                const V8 kf = *(const V8*)(sb + c * 4096 + (kaddr0 ^ (ks << 5)));
+                const V8 kf = *(const V8*)(sb + dsub + c * 4096 + (kaddr0 ^ (ks << 5)));
                 if (NT > 1) {
-                    const V8 kl = *(const V8*)(sb + 2 * TILE + c * 4096 + (kaddr0 ^ (ks << 5)));
+                    const V8 kl = *(const V8*)(sb + 2 * TILE + dsub + c * 4096 + (kaddr0 ^ (ks << 5)));
 #endif
 #ifndef AMX_ATTN_ABL_NOCROSS  // developer ablation (results lose the lo planes): a third of the MFMAs, same loads
-                    X[c] = mfma32(kl, qf[0][ks], X[c]);
-                    X[c] = mfma32(kf, qf[NT - 1][ks], X[c]);
+                    X[c] = mfma32(kl, qf[0][kq], X[c]);
+                    X[c] = mfma32(kf, qf[NT - 1][kq], X[c]);
 #else
                     asm volatile("" ::"v"(kl));
 #endif
                 }
-                X[c] = mfma32(kf, qf[0][ks], X[c]);
+                X[c] = mfma32(kf, qf[0][kq], X[c]);
             }
         }
         ATTN_STAMP(st_s, st_prev)
@@ -298,7 +315,9 @@ __global__ __launch_bounds__(WAVES * KS * 64, AMX_ATTN_OCC) void attn_kernel(con
             m_run += d;
             l_run *= alpha;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { O[0][r] *= alpha; O[1][r] *= alpha; }
+            for (int b = 0; b < 2 * NDH; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) O[b][r] *= alpha;
 #pragma unroll
             for (int c = 0; c < NC; ++c)
 #pragma unroll
@@ -347,21 +366,22 @@ __global__ __launch_bounds__(WAVES * KS * 64, AMX_ATTN_OCC) void attn_kernel(con
                 const int koff = c * 4096 + s2 * 2048;  // key rows 32c + 16s2 (+ 8g)
 #endif
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
+                for (int ob = 0; ob < 2 * NDH; ++ob) {
+                    const int dt = ob & 1, vsub = (ob >> 1) * SUB + koff;  // 32-column block `dt` of V sub-tile ob / 2
                     union { s16x4 h[2]; V8 v; } vf, vl;
-                    vf.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(sb + koff + vaddr[dt]));
-                    vf.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(sb + koff + 1024 + vaddr[dt]));
+                    vf.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(sb + vsub + vaddr[dt]));
+                    vf.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(sb + vsub + 1024 + vaddr[dt]));
                     if (NT > 1) {
-                        vl.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(sb + 2 * TILE + koff + vaddr[dt]));
-                        vl.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(sb + 2 * TILE + koff + 1024 + vaddr[dt]));
+                        vl.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(sb + 2 * TILE + vsub + vaddr[dt]));
+                        vl.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(sb + 2 * TILE + vsub + 1024 + vaddr[dt]));
 #ifndef AMX_ATTN_ABL_NOCROSS
-                        O[dt] = mfma32(vl.v, ph.v, O[dt]);
-                        O[dt] = mfma32(vf.v, pl_.v, O[dt]);
+                        O[ob] = mfma32(vl.v, ph.v, O[ob]);
+                        O[ob] = mfma32(vf.v, pl_.v, O[ob]);
 #else
                         asm volatile("" ::"v"(vl.v), "v"(pl_.v));
 #endif
                     }
-                    O[dt] = mfma32(vf.v, ph.v, O[dt]);
+                    O[ob] = mfma32(vf.v, ph.v, O[ob]);
                 }
             }
         // tile kt+1 has landed (this wave's pieces) and this wave's LDS reads of tile kt have RETURNED: the first thing any
@@ -411,7 +431,39 @@ __global__ __launch_bounds__(WAVES * KS * 64, AMX_ATTN_OCC) void attn_kernel(con
 #endif
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
-    if constexpr (TSTORE) {
+    if (NDH > 1 || p.dh != DH) {
+        // head dimensions other than 64: only the dh real columns of the padded O leave, four at a time (dh % 8 == 0: a quad lies
+        // wholly inside or wholly outside), each quad mapped through pidx() -- heads need not start on a 32-column block
+        if (query < (packed ? klen : p.T)) {
+            const bool o_il = plane_is_il<NT>(p.out_plane);
+            const int64_t col0 = ((packed ? (int64_t)roff : (int64_t)n * p.T) + query) * ((int64_t)p.H * p.dh) + (int64_t)h * p.dh;
+#pragma unroll
+            for (int ob = 0; ob < 2 * NDH; ++ob)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d0 = ob * 32 + 8 * g + 4 * hh;
+                    if (d0 < p.dh) {
+                        V4 hv, lv;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            T hi, lo = (T)0.f;
+                            split16<T, NT>(O[ob][4 * g + j] * inv, hi, lo);
+                            hv[j] = hi;
+                            lv[j] = lo;
+                        }
+                        T* dst = (T*)p.out + pidx(col0 + d0, o_il);
+                        *(V4*)dst = hv;
+                        if (NT > 1) *(V4*)(dst + p.out_plane) = lv;
+                    }
+                }
+        }
+#ifdef AMX_ATTN_STAMP
+        goto attn_stamp_out;
+#else
+        return;
+#endif
+    }
+    if constexpr (TSTORE && NDH == 1) {
         const bool o_il = plane_is_il<NT>(p.out_plane);
         if (NT == 1 || o_il) {  // (separate hi / lo planes -- non-wav2vec 2.0 widths -- keep the direct stores below)
             constexpr int ROW = NT == 2 ? 256 : 128, CH = ROW / 16;  // bytes / 16-byte chunks of one query's head segment
@@ -454,7 +506,7 @@ __global__ __launch_bounds__(WAVES * KS * 64, AMX_ATTN_OCC) void attn_kernel(con
 #endif
         }
     }
-    if (query < (packed ? klen : p.T)) {
+    if (NDH == 1 && query < (packed ? klen : p.T)) {
         // (the output feeds the out-projection GEMM: interleaved planes in the two-plane modes, amx_common.h pidx())
         const bool o_il = plane_is_il<NT>(p.out_plane);
         T* dst = (T*)p.out + pidx(((packed ? (int64_t)roff : (int64_t)n * p.T) + query) * (p.H * DH) + h * DH, o_il);
@@ -893,8 +945,31 @@ void launch_attn(const AttnParams& p, hipStream_t stream) {
 
 }  // namespace
 
+// head dimensions other than 64 (AttnParams.dh; rows padded to dhp = 64 or 128): 8-wave workgroups, masked direct stores
+template <typename T, int NT, bool PACKED, int NDH>
+void launch_attn_other_dh(const AttnParams& p, hipStream_t stream) {
+    constexpr int WAVES = 8, KT = 64;
+    constexpr int lds = 2 * NT * 2 * KT * 128 * NDH;
+    static OncePerDevice attr;
+    if (attr.first())
+        (void)hipFuncSetAttribute((const void*)attn_kernel<T, NT, WAVES, KT, PACKED, 1, false, NDH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const int qblocks = (p.T + WAVES * 32 - 1) / (WAVES * 32);
+    dim3 grid((unsigned)(8 * ((p.N * p.H + 7) / 8) * qblocks));
+    hipLaunchKernelGGL((attn_kernel<T, NT, WAVES, KT, PACKED, 1, false, NDH>), grid, dim3(WAVES * 64), lds, stream, p);
+}
+
 template <typename T, int NT>
 void launch_attn_any(const AttnParams& p, hipStream_t stream) {
+    if (p.dh != DH) {
+        if (p.dhp > 64) {
+            if (p.row_off) launch_attn_other_dh<T, NT, true, 2>(p, stream);
+            else launch_attn_other_dh<T, NT, false, 2>(p, stream);
+        } else {
+            if (p.row_off) launch_attn_other_dh<T, NT, true, 1>(p, stream);
+            else launch_attn_other_dh<T, NT, false, 1>(p, stream);
+        }
+        return;
+    }
     // Short batches (e.g. 4 x 10 s: 64 (utterance, head) pairs x 2 blocks of 256 queries) leave most CUs without a
     // workgroup while the busy ones run two waves per SIMD: with 128-query workgroups of 4 waves the same waves spread over
     // twice as many CUs, one per SIMD.  Each query's arithmetic is identical in both forms (bitwise equal outputs).

@@ -72,6 +72,19 @@ __device__ __forceinline__ void dma16(dma_rsrc_t rsrc, const void* lds_dst, uint
 }
 #endif
 
+#ifdef __HIPCC__
+// s_waitcnt lgkmcnt(0) -- every LDS read of the wave has returned -- through the BUILTIN (vmcnt / expcnt fields all-ones: no wait on
+// them), i.e. as an instruction the compiler's wait-count pass sees.  An inline-asm wait is opaque to that pass: behind it the pass
+// still believes the fragment reads of a K slice to be in flight and, depending on nothing one can control from the source, either
+// adds ONE lgkmcnt(0) behind the barrier or re-waits for every fragment inside the MFMA segment -- 12 s_waitcnt between the 96
+// MFMAs of a slice, ~ 3.5 % of every product (round 6: the conv kernel had carried them since round 3, the ping-pong kernel picked
+// them up as soon as its epilogues changed).  The empty asm keeps the "memory" clobber the asm form had.
+__device__ __forceinline__ void lgkm_wait0() {
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    asm volatile("" ::: "memory");
+}
+#endif
+
 __host__ __device__ __forceinline__ int64_t pidx(int64_t o, bool il) { return il ? (((o >> 5) << 6) | (o & 31)) : o; }
 template <int NT>
 __host__ __device__ __forceinline__ bool plane_is_il(int64_t plane) { return NT > 1 && plane == PLANE_IL; }
@@ -247,6 +260,7 @@ struct GemmParams {
     void* v;
     int64_t qk_plane;  // plane distance of q, k and v
     int T, Tp, H, dh;
+    int dhp;  // elements per row of q / k / v (>= dh: 64 or 128; the scatter never writes columns [dh, dhp), which stay zero)
     // fused LayerNorm over the N outputs of a row + GELU (gemm_fuses_ln(); the row-complete 128 x 512 kernel, N == 512)
     const float* ln_gamma;
     const float* ln_beta;
@@ -327,6 +341,7 @@ struct AttnParams {
     int64_t out_plane;
     const int* frame_len;  // [N] valid keys per utterance
     int N, H, T, Tp, dh;
+    int dhp;  // elements per Q / K / V row: 64 for dh <= 64, 128 for dh in (64, 128]; columns [dh, dhp) hold zeros
     // packed rows (null: padded layout as described above).  With row_off the utterances lie back to back: Q / K / V are
     // [H, Tp, dh] planes in which utterance n owns rows row_off[n] .. row_off[n] + frame_len[n] (Tp = rows per head, at
     // least 64 finite rows beyond the last utterance), `out` is [sum(frame_len), D] and only valid queries are computed

@@ -11,6 +11,8 @@ Linear-shaped product of a layer as hi.hi + lo.hi + hi.lo on f16 planes with fp3
             apply  y = alpha_m * acc + beta_m * c_n + d_n  with alpha = rstd / s, beta = -rstd * (mu - p),
             c = W gamma, d = W beta + b (fp64 at create)
   fold_nopivot   the same with p = 0 and s = 1 (what a pivot-free form would do; DC offsets then cancel in fp32 after the product)
+  fold_planes    fold, with the residual stream kept ONLY as those planes between the products (no fp32 copy: the next residual is
+                 (hi + lo) / s + p) -- not built; priced here
 
 Weight families: those of tests/test_gpu_range.py (plain, scales, student_t, ln_gain, outlier) plus `dc30`: every row of the
 residual stream carries a DC offset of ~ 30 sigma.
@@ -84,7 +86,8 @@ def encoder_layers(h, bias, state, spec, scheme):
     dh = D // H
     hidden = []
     fold = scheme.startswith("fold")
-    pivot = scheme == "fold"
+    pivot = scheme in ("fold", "fold_planes")
+    planes_only = scheme == "fold_planes"
     x = h.reshape(N * T, D).clone()
     M = x.shape[0]
     if fold:
@@ -116,6 +119,8 @@ def encoder_layers(h, bias, state, spec, scheme):
         nonlocal x, u, p, s, alpha, beta
         v = x3(a, state[prefix + ".weight"]) + state[prefix + ".bias"] + x
         x = v
+        if planes_only:
+            pass  # (x is replaced by what the planes hold once they are formed below)
         if fold:
             e = v - p[:, None]
             u = e * s[:, None]
@@ -123,6 +128,10 @@ def encoder_layers(h, bias, state, spec, scheme):
             rstd = 1.0 / torch.sqrt(var + eps)
             alpha = rstd / s
             beta = -rstd * m1
+            if planes_only:
+                # the stream exists as planes only: the next residual is what they hold, under the pivot / scale they were written with
+                uh, ul = split(u)
+                x = (uh + ul) / s[:, None] + p[:, None]
             if pivot:
                 # what the NEXT producer writes its planes under
                 p = p + m1
@@ -196,7 +205,7 @@ def main():
         row = hid[2].reshape(-1, hid[2].shape[-1])
         ratio = (row.mean(-1).abs() / row.std(-1)).median().item()
         line = f"{fam:10s} |mean|/sigma of stream rows (layer 2) = {ratio:6.2f}  "
-        for scheme in ("current", "fold", "fold_nopivot"):
+        for scheme in ("current", "fold", "fold_nopivot", "fold_planes"):
             got, _, _ = run(audio, lengths, state, spec, tfi, offsets, scheme)
             worst = 0.0
             for k_ in exact:
