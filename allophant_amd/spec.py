@@ -81,7 +81,7 @@ def tiny_encoder(layers: int = 2) -> Dict[str, Any]:
         "conv_dim": 32,
         "conv_kernel": [10, 3, 3, 3, 3, 2, 2],
         "conv_stride": [5, 2, 2, 2, 2, 2, 2],
-        "hidden": 128,  # head_dim 64 like XLS-R (the attention kernel is specialised for it)
+        "hidden": 128,  # head_dim 64 like XLS-R (other head dimensions: goldens g13 / g13b)
         "layers": layers,
         "heads": 2,
         "ffn": 256,
@@ -302,6 +302,8 @@ def validate(spec: Dict[str, Any]) -> None:
     evaluation_order(spec["classes"])
     if spec["hidden"] % spec["heads"] != 0:
         raise ValueError("hidden must be divisible by heads")
+    if (spec["hidden"] // spec["heads"]) % 8 or spec["hidden"] // spec["heads"] > 128:
+        raise ValueError("head_dim (hidden / heads) must be a multiple of 8 and at most 128 (amx_create)")
     if spec.get("feat_extract_norm", "layer") not in ("layer", "group"):
         # transformers' own message (Wav2Vec2FeatureEncoder.__init__)
         raise ValueError(f"`config.feat_extract_norm` is {spec['feat_extract_norm']}, but has to be one of ['group', 'layer']")

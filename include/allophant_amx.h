@@ -93,7 +93,8 @@ typedef struct amx_config {
     int32_t conv_stride[AMX_MAX_CONV];   /* 5,2,2,2,2,2,2 */
     int32_t hidden;                      /* 1024 */
     int32_t layers;                      /* 24 */
-    int32_t heads;                       /* 16 (head_dim must be 64) */
+    int32_t heads;                       /* 16 (head_dim = hidden / heads: a multiple of 8, at most 128 -- 64 for every released
+                                            checkpoint, 80 / 120 for XLS-R 1B / 2B shapes; ABI 6) */
     int32_t ffn;                         /* 4096 */
     int32_t pos_kernel;                  /* 128 */
     int32_t pos_groups;                  /* 16 */

@@ -221,7 +221,7 @@ def integer_goldens():
 
 def main():
     torch.set_num_threads(8)
-    which = set(sys.argv[1:]) or {"g1", "g2", "g2b", "g3", "g4", "g5", "g8", "g11", "g11b", "g12"}
+    which = set(sys.argv[1:]) or {"g1", "g2", "g2b", "g3", "g4", "g5", "g8", "g11", "g11b", "g12", "g13", "g13b"}
     tiny = S.tiny_encoder(2)
     if "g4" in which:
         integer_goldens()
@@ -300,6 +300,26 @@ def main():
         spec["shared_phones"] = 80
         run_case("g12_w2v2base_multitask", spec, n=2, length=48000, ragged=True, inventory_phones=27, seed=0,
                  store_weights=False, subsample=[0, 1, 6, 12], store_audio=False)
+    if "g13" in which:
+        # G13 (round 6): head_dim != 64.  The reference builds whatever `model_id` names (acoustic_model.py:796-826): XLS-R 1B / 2B
+        # have head dimensions 80 / 120.  Tiny shape with hidden 160 / 2 heads = head_dim 80 (rows of Q / K / V padded to 128 on the
+        # device), hierarchical graph with an OUTPUT_i dependency, ragged batch
+        enc = S.tiny_encoder(2)
+        enc.update(hidden=160, heads=2, ffn=320, pos_groups=4)
+        spec = S.multitask_spec(enc, ["syllabic", "long"], embedding_size=16, train_phonemes=9, n_features=5, allophone_layer=True)
+        spec["shared_phones"] = 11
+        spec["classes"] = [
+            {"name": "syllabic", "size": 3, "dependencies": ["OUTPUT_1"]},
+            {"name": "long", "size": 2, "dependencies": ["OUTPUT"]},
+            {"name": "phoneme", "size": 9, "dependencies": ["OUTPUT", "syllabic", "long"]},
+        ]
+        run_case("g13_tiny_head_dim_80", spec, n=3, length=6400, ragged=True, inventory_phones=7, seed=13, store_weights=False)
+    if "g13b" in which:
+        # G13b: head_dim 32 (hidden 64 / 2 heads: narrower than the 64-column rows of the device layout), post-LN variant
+        enc = S.tiny_encoder(2)
+        enc.update(hidden=64, heads=2, ffn=128, pos_groups=4, stable_layer_norm=False)
+        spec = S.multitask_spec(enc, ["syllabic", "long", "nasal"], embedding_size=16, train_phonemes=9, n_features=5)
+        run_case("g13b_tiny_head_dim_32", spec, n=2, length=5200, ragged=True, inventory_phones=6, seed=14, store_weights=False)
     if "g3" in which:
         # G3: full XLS-R shape, procedural weights (seed 0), 2 x 3 s ragged; sub-sampled tensors only
         spec = S.multitask_spec(S.xlsr_300m_encoder(), allophone_layer=True)

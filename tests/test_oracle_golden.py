@@ -18,7 +18,9 @@ TINY = ["g1_tiny_multitask", "g2_tiny_hierarchical", "g2b_tiny_hierarchical_blan
         "g8_tiny_time_layer",  # g8: time-layer (ProjectingMultiheadAttention) classifiers, with and without positions
         # the group-norm / post-LN wav2vec 2.0 variant (wav2vec2-base / -large): g11 as the reference runs such a model
         # (attention_mask=None), g11b with the attention mask and a conv bias
-        "g11_tiny_groupnorm_postln", "g11b_tiny_groupnorm_masked"]
+        "g11_tiny_groupnorm_postln", "g11b_tiny_groupnorm_masked",
+        # head dimensions other than 64 (round 6): 80 (XLS-R 1B's) and 32
+        "g13_tiny_head_dim_80", "g13b_tiny_head_dim_32"]
 
 
 @pytest.mark.parametrize("name", TINY)
