@@ -182,7 +182,12 @@ void launch_pp_fold(const GemmParams& p, hipStream_t stream) {
 }
 
 template <typename T, int NT, int MI, int NI = 4>
-void launch_pp_tiles(const GemmParams& p, int splits, hipStream_t stream) {
+void launch_pp_tiles(const GemmParams& p_in, int splits, hipStream_t stream) {
+    // developer timing switches (WRONG results: the fold's products run as plain products, to price its epilogues one side at a time)
+    static const bool producer_plain = dev_switch("AMX_FOLD_PRODUCER_PLAIN"), consumer_plain = dev_switch("AMX_FOLD_CONSUMER_PLAIN");
+    GemmParams p = p_in;
+    if (producer_plain && p.ln_partial) { p.ln_partial = nullptr; p.ln_rowps = nullptr; p.out_p = nullptr; }
+    if (consumer_plain && p.row_coef) { p.row_coef = nullptr; p.col_c = nullptr; }
     if (p.ln_partial) {
         if constexpr (NI == 4) launch_pp_fold<T, NT, MI, 4, 2>(p, stream);
         return;
