@@ -186,11 +186,19 @@ struct amx_handle_s {
         int* host = nullptr;
         hipEvent_t ev = nullptr;
         bool pending = false, cont = false;
+        uint64_t pass_id = 0;  // which amx_forward of this handle the reading belongs to (amx_pass_info: AMX_PASS_INFO_ID)
     };
     static constexpr int RANGE_SLOTS = 8;
     RangeSlot range[RANGE_SLOTS];
     int range_next = 0;
     int64_t range_carry = 0;  // count of a slot that had to be reused before any call had read it
+    std::string range_carry_ids;  // ... and the passes it belonged to
+    uint64_t pass_counter = 0;    // passes issued so far (the id of the last one)
+    // the slices of one over-long batch (AMX_FLAG_CONTINUE) share ONE running device counter: the reading of a slice includes its
+    // predecessors'.  What the last poll saw of a chain whose later slices were not ready yet, so that the next poll counts the
+    // difference only (round-5 advisor finding: a chain read across two polls used to be counted twice)
+    int range_chain_seen = 0;
+    bool range_chain_open = false;
     // last forward geometry
     int last_N = 0;
     bool last_fold = false;  // amx_pass_info: the last pass ran its encoder layers with the LayerNorm fold ...
@@ -465,7 +473,9 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
     h->masked = cfg->use_attention_mask != 0;
     {
         static const bool plain = dev_switch("AMX_PLAIN_PLANES");  // developer A/B switch
-        h->il = h->NT > 1 && !plain && cfg->conv_dim % 32 == 0 && cfg->ffn % 32 == 0;
+        // (hidden too -- round 6: the residual-stream planes [M, hidden] are GEMM operands like the others; a hidden size off the
+        // 32-element blocks -- 240 = 2 heads of 120 -- ran interleaved planes through kernels that assume block-aligned rows)
+        h->il = h->NT > 1 && !plain && cfg->conv_dim % 32 == 0 && cfg->ffn % 32 == 0 && cfg->hidden % 32 == 0;
     }
     h->classes.assign(classes, classes + n_classes);
     auto bail = [&](int code) {
@@ -1169,9 +1179,9 @@ static void drop_graphs(amx_handle h) {
 // of every pass issued -- the caller has just synchronised or accepts to).  Returns AMX_ERANGE when one of them counted valid
 // frames with non-finite logits; the report is consumed by the call that returns it.
 static int range_poll(amx_handle h, bool wait) {
+    // (one handle = one stream, include/allophant_amx.h: passes complete in issue order, so the slots are read oldest first and the
+    // first one that is not ready ends the poll)
     int64_t total = 0;
-    int prev_count = 0;
-    bool have_prev = false;
     std::string readings;
     for (int i = 0; i < amx_handle_s::RANGE_SLOTS; ++i) {
         auto& sl = h->range[(h->range_next + i) % amx_handle_s::RANGE_SLOTS];  // oldest first
@@ -1180,24 +1190,32 @@ static int range_poll(amx_handle h, bool wait) {
             HIPCHK(h, hipEventSynchronize(sl.ev));
         } else {
             const hipError_t q = hipEventQuery(sl.ev);
-            if (q == hipErrorNotReady) break;  // passes complete in issue order on a stream: nothing later is ready either
+            if (q == hipErrorNotReady) break;
             if (q != hipSuccess) { (void)hipGetLastError(); break; }
         }
         sl.pending = false;
-        // the slices of one over-long batch (AMX_FLAG_CONTINUE) share a running count: only its last reading is a total
-        if (have_prev && !sl.cont) total += prev_count;
-        prev_count = *sl.host;
-        have_prev = true;
-        readings += (readings.empty() ? "" : ", ") + std::to_string(prev_count) + (sl.cont ? "c" : "");
+        // a continuation slice's reading is the chain's running count: what it adds is the difference to its predecessor's reading
+        const int reading = *sl.host;
+        const int added = sl.cont && h->range_chain_open ? reading - h->range_chain_seen : reading;
+        h->range_chain_seen = reading;
+        h->range_chain_open = true;
+        if (added > 0) {
+            total += added;
+            readings += (readings.empty() ? "" : ", ") + std::string("pass #") + std::to_string(sl.pass_id) + ": " + std::to_string(added);
+        }
     }
-    if (have_prev) total += prev_count;
-    total += h->range_carry;
+    if (h->range_carry > 0) {
+        total += h->range_carry;
+        readings += (readings.empty() ? "" : ", ") + h->range_carry_ids;
+    }
     h->range_carry = 0;
+    h->range_carry_ids.clear();
     if (total > 0)
         return fail(h, AMX_ERANGE, std::to_string(total) + " valid frame(s) of an EARLIER forward pass hold non-finite logits: an activation left the "
                                    "range of the 16-bit planes (fp16: |x| <= 65504) or the input was not finite; the outputs of that pass "
                                    "are not usable.  The bf16 planes (precision bf16x3) have the range of fp32; AMX_FLAG_NO_RANGE_CHECK "
-                                   "turns this report off (counts of the passes read, oldest first: " + readings + ")");
+                                   "turns this report off (frames per offending pass -- passes are numbered from 1 per handle, the one being "
+                                   "issued now would be #" + std::to_string(h->pass_counter + 1) + " -- " + readings + ")");
     return AMX_OK;
 }
 
@@ -1212,13 +1230,21 @@ static int range_record(amx_handle h, bool cont, hipStream_t s) {
         // RANGE_SLOTS passes ago and never read since (the host ran that far ahead): wait for that pass and carry its count
         // into the next report instead of losing it
         HIPCHK(h, hipEventSynchronize(sl.ev));
-        h->range_carry += *sl.host;
+        const int reading = *sl.host;
+        const int added = sl.cont && h->range_chain_open ? reading - h->range_chain_seen : reading;
+        h->range_chain_seen = reading;
+        h->range_chain_open = true;
+        if (added > 0) {
+            h->range_carry += added;
+            h->range_carry_ids += (h->range_carry_ids.empty() ? "" : ", ") + std::string("pass #") + std::to_string(sl.pass_id) + ": " + std::to_string(added);
+        }
         sl.pending = false;
     }
     HIPCHK(h, hipMemcpyAsync(sl.host, h->nonfinite, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipEventRecord(sl.ev, s));
     sl.pending = true;
     sl.cont = cont;
+    sl.pass_id = h->pass_counter;
     h->range_next = (h->range_next + 1) % amx_handle_s::RANGE_SLOTS;
     return AMX_OK;
 }
@@ -1597,6 +1623,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         fold = gemm_ln_fold_ok(prec, as_consumer(qkv_params(ly), ly.c_qkv)) && gemm_ln_fold_ok(prec, as_producer(oproj_params(ly))) &&
                gemm_ln_fold_ok(prec, as_consumer(ffn1_params(ly), ly.c_1)) && gemm_ln_fold_ok(prec, as_producer(ffn2_params(ly)));
     }
+    ++h->pass_counter;
     h->last_fold = fold;
     h->last_packed = packed_early ? 2 : (packed ? 1 : 0);
     h->last_rows = Mrows;
@@ -2029,6 +2056,8 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         HIPCHK(h, hipMemcpyAsync(out, d_out, (size_t)total * 4, hipMemcpyDeviceToHost, s));
         HIPCHK(h, hipStreamSynchronize(s));
     }
+    bool report_now = false;
+    if ((flags & AMX_FLAG_HOST_IO) && !(flags & AMX_FLAG_NO_RANGE_CHECK)) report_now = true;
     h->last_N = N; h->last_L = L; h->last_T = T; h->last_keep = keep;
     h->last_packed_rows = packed_early;
     if (packed_early) {
@@ -2037,13 +2066,15 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     }
     h->qkv_dirty = packed;  // a packed call leaves other rows in the Q / K / V planes: the next padded call re-zeroes them
 #undef WS
+    // a host-I/O call has synchronised and handed the outputs over already: its own range report does not wait for the next call
+    if (report_now && (rc = range_poll(h, true))) return rc;
     return AMX_OK;
 }
 
 extern "C" int amx_pass_info(amx_handle h, int32_t* info, int n) {
     if (!h || !info || n < 0) return AMX_EINVAL;
     const int32_t values[AMX_PASS_INFO_COUNT] = {h->last_fold ? 1 : 0, h->last_packed, h->last_graph,
-                                                 (int32_t)std::min<int64_t>(h->last_rows, INT32_MAX)};
+                                                 (int32_t)std::min<int64_t>(h->last_rows, INT32_MAX), (int32_t)(h->pass_counter & 0x7fffffff)};
     for (int i = 0; i < n && i < AMX_PASS_INFO_COUNT; ++i) info[i] = values[i];
     return AMX_OK;
 }

@@ -21,7 +21,7 @@ PRECISIONS = {"bf16": 0, "f16": 1, "bf16x3": 2, "f16x3": 3}
 FLAG_HOST_IO, FLAG_RAW_LOGITS, FLAG_KEEP_HIDDEN, FLAG_TIMING, FLAG_PADDED, FLAG_NO_PACK, FLAG_CONTINUE = 1, 2, 4, 8, 16, 32, 64
 FLAG_NO_GRAPH, FLAG_NO_RANGE_CHECK = 128, 256
 NORM_LAYER, NORM_GROUP = 0, 1
-PASS_INFO = ["ln_fold", "packed", "graph", "rows"]  # AMX_PASS_INFO_*
+PASS_INFO = ["ln_fold", "packed", "graph", "rows", "id"]  # AMX_PASS_INFO_*
 KERNEL_CLASSES = ["gemm_pp", "gemm_tile", "attention", "rownorm", "conv0", "other", "gemm_ln", "conv_tail"]
 DEP_OUTPUT = -1
 

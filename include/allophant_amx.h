@@ -207,7 +207,9 @@ int amx_graph_info(amx_handle h, int64_t* captures, int64_t* replays);
 #define AMX_PASS_INFO_PACKED 1    /* 0: padded rows; 1: encoder layers on the valid frames only; 2: packed from the feature projection on */
 #define AMX_PASS_INFO_GRAPH 2     /* 0: enqueued launch by launch; 1: recorded into a HIP graph by this call; 2: replayed from one */
 #define AMX_PASS_INFO_ROWS 3      /* rows (frames) the encoder layers worked on */
-#define AMX_PASS_INFO_COUNT 4
+#define AMX_PASS_INFO_ID 4        /* number of the pass among the amx_forward calls of this handle (from 1; low 31 bits): an AMX_ERANGE
+                                     report names the offending pass by this number */
+#define AMX_PASS_INFO_COUNT 5
 int amx_pass_info(amx_handle h, int32_t* info, int n);
 
 /* Range check of the last amx_forward on `stream` (no upstream counterpart: the reference computes in fp32).  The 16-bit
