@@ -1610,13 +1610,23 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         g.row_coef = (const float2*)ln_coef; g.col_c = col_c;
         return g;
     };
-    auto as_producer = [&](GemmParams g) {
-        g.ln_partial = (float2*)ln_partial; g.ln_rowps = (const float2*)ln_rowps;
+    // Two-plane modes: between the products of a layer the stream lives in its planes only -- a producer reads its residual from
+    // them and writes fp32 rows only where something reads those (`f32`: a published hidden state, the last layer: the final
+    // LayerNorm and the unpacking read fp32).  AMX_FOLD_F32_STREAM=1: developer A/B switch (fp32 rows in and out of every producer).
+    static const bool f32_stream = dev_switch("AMX_FOLD_F32_STREAM");
+    const bool stream_in_planes = NT == 2 && !f32_stream;
+    auto as_producer = [&](GemmParams g, bool f32 = true) {
+        g.ln_partial = (float2*)ln_partial; g.ln_rowps = (const float4*)ln_rowps;
         g.out_p = xp; g.out_plane = xp_plane; g.ldp = D;
+        if (stream_in_planes) {
+            g.ln_res_planes = 1;
+            g.residual = nullptr;
+            if (!f32) g.out_f32 = nullptr;
+        }
         return g;
     };
     if (stable && !no_ln_fold && c.layers > 0 && D % 64 == 0 && D <= 1024) {
-        WS("ln_rowps", (size_t)Mrows * 8, ln_rowps);
+        WS("ln_rowps", (size_t)Mrows * 16, ln_rowps);
         WS("ln_coef", (size_t)Mrows * 8, ln_coef);
         WS("ln_partial", (size_t)Mrows * (D / 64) * 8, ln_partial);
         const Layer& ly = h->layers[0];
@@ -1829,7 +1839,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     // normalises with (1, 0))
     auto ln_finalize = [&]() {
         Timed t_(h, AMX_KC_ROWNORM);
-        launch_ln_finalize((const float2*)ln_partial, D / 64, Mrows, c.eps, (float2*)ln_rowps, (float2*)ln_coef, s);
+        launch_ln_finalize((const float2*)ln_partial, D / 64, Mrows, c.eps, (float4*)ln_rowps, (float2*)ln_coef, s);
     };
     for (int l = 0; l < c.layers; ++l) {
         const Layer& ly = h->layers[l];
@@ -1837,7 +1847,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             // the first norm of the stack from the stream itself; later ones: the previous FFN2 left planes and statistics
             if (l == 0) {
                 Timed t_(h, AMX_KC_ROWNORM);
-                launch_ln_rowprep(prec, (const float*)hbuf, D, Mrows, D, c.eps, xp, xp_plane, D, (float2*)ln_rowps, (float2*)ln_coef, s);
+                launch_ln_rowprep(prec, (const float*)hbuf, D, Mrows, D, c.eps, xp, xp_plane, D, (float4*)ln_rowps, (float2*)ln_coef, s);
             }
         } else if (stable) {
             stream_norm(h->unit_g, h->zero_b, Mrows, xp_plane, nullptr);  // (completes the previous layer's FFN2 when that was deferred)
@@ -1870,7 +1880,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             { Timed t_(h, AMX_KC_ATTENTION); launch_attention(prec, a, s); }
         }
         if (fold) {
-            residual_gemm(as_producer(oproj_params(ly)), false);
+            residual_gemm(as_producer(oproj_params(ly), false), false);  // (nothing reads the stream between the two halves of a layer)
             ln_finalize();
         } else {
             residual_gemm(oproj_params(ly), true);
@@ -1883,9 +1893,12 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             if (fold) g = as_consumer(g, ly.c_1);
             { Timed t_(h, gemm_class(prec, g)); launch_gemm(prec, g, s); }
         }
-        if (fold && l + 1 < c.layers) {
-            residual_gemm(as_producer(ffn2_params(ly)), false);
-            ln_finalize();
+        if (fold && (l + 1 < c.layers || stream_in_planes)) {
+            // fp32 rows where the next reader needs them: hidden state l + 1 is published, or this is the last layer (final LayerNorm,
+            // unpacking); the last layer's planes and statistics have no reader (it is a producer for the residual's sake)
+            const bool last = l + 1 == c.layers;
+            residual_gemm(as_producer(ffn2_params(ly), last || saved[l + 1] != nullptr), false);
+            if (!last) ln_finalize();
         } else {
             // (the last layer of a packed batch is followed by the unpacking, not by a LayerNorm of these rows)
             residual_gemm(ffn2_params(ly), !fold && !(packed && !packed_early && l == c.layers - 1));

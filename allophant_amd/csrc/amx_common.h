@@ -299,8 +299,14 @@ struct GemmParams {
     // is from the mean) into row_coef[m] = (rstd / s_m, -rstd * (mu - p_m)) and moves ln_rowps on.  CONSUMER (QKV, FFN1;
     // row_coef != null): A = the planes of u, W = gamma (.) W packed at amx_create, bias = d, and the epilogue computes
     // v = alpha_m * (acc * scale) + beta_m * col_c[n] + bias[n].
-    const float2* ln_rowps;   // producer: [M] (pivot, scale)
+    const float4* ln_rowps;   // producer: [M] (pivot, scale) of the planes the row holds NOW, (pivot, scale) they are written under next
     float2* ln_partial;       // producer: [M][N / 64]
+    // producer, two-plane modes: the residual is read from the stream's own planes (out_p, in place, under the first pair of
+    // ln_rowps) instead of the fp32 rows, and out_f32 may be null: between the products of a layer the stream then exists as planes
+    // only (22 significant bits about the row's pivot: emulated in tests/diagnostics/emulate_ln_fold.py, `fold_planes`) and the
+    // fp32 copy is written where something reads it -- 65 MB less per product at config 2, the tail of these kernels being a pure
+    // HBM burst (profiles/r06_per_product_durations.log)
+    int ln_res_planes;
     const float2* row_coef;   // consumer: [M] (alpha, beta)
     const float* col_c;       // consumer: [N]
 };
@@ -391,13 +397,13 @@ void launch_rownorm(int prec, const float* x, int64_t ldx, int64_t M, int D, con
                     int64_t out_plane, int64_t ldp, float* out_f32, int64_t ldo, hipStream_t s);
 // LayerNorm fold (GemmParams.ln_partial / row_coef): the FIRST norm of the encoder stack, from the fp32 stream itself: exact row
 // statistics (two passes over the row in registers, like launch_rownorm) -> planes of u = (x - mu) * s with s the power of two
-// that puts 16 / sigma ... 8 / sigma into it, rowps[m] = (mu, s), coef[m] = (rstd / s, 0)
+// that puts 16 / sigma ... 8 / sigma into it, rowps[m] = (mu, s, mu, s), coef[m] = (rstd / s, 0)
 void launch_ln_rowprep(int prec, const float* x, int64_t ldx, int64_t M, int D, float eps, void* out_p, int64_t out_plane, int64_t ldp,
-                       float2* rowps, float2* coef, hipStream_t s);
+                       float4* rowps, float2* coef, hipStream_t s);
 // merges the per-block statistics a producer left in `partial` [M][blocks] (of v - pivot, 64 columns per block) into
-// coef[m] = (rstd / s_m, -rstd * (mu - p_m)) for the consumer of those planes, then moves rowps[m] on to (mu, scale of the new rstd)
-// for the next producer
-void launch_ln_finalize(const float2* partial, int blocks, int64_t M, float eps, float2* rowps, float2* coef, hipStream_t s);
+// coef[m] = (rstd / s_m, -rstd * (mu - p_m)) for the consumer of those planes, then moves rowps[m] on: the pair the producer wrote
+// under becomes "what the planes hold now", (mu, scale of the new rstd) what the next producer writes under
+void launch_ln_finalize(const float2* partial, int blocks, int64_t M, float eps, float4* rowps, float2* coef, hipStream_t s);
 // the same with the rows of a ragged batch gathered on the way out: input row n * T_rows + t -> plane row row_off[n] + t,
 // frames t >= frame_len[n] dropped (the feature projection of a ragged batch then runs on the valid frames only)
 void launch_rownorm_to_packed(int prec, const float* x, int64_t ldx, int64_t M, int D, const float* gamma1, const float* beta1,

@@ -186,7 +186,7 @@ void launch_pp_tiles(const GemmParams& p_in, int splits, hipStream_t stream) {
     // developer timing switches (WRONG results: the fold's products run as plain products, to price its epilogues one side at a time)
     static const bool producer_plain = dev_switch("AMX_FOLD_PRODUCER_PLAIN"), consumer_plain = dev_switch("AMX_FOLD_CONSUMER_PLAIN");
     GemmParams p = p_in;
-    if (producer_plain && p.ln_partial) { p.ln_partial = nullptr; p.ln_rowps = nullptr; p.out_p = nullptr; }
+    if (producer_plain && p.ln_partial) { p.ln_partial = nullptr; p.ln_rowps = nullptr; p.out_p = nullptr; p.ln_res_planes = 0; }
     if (consumer_plain && p.row_coef) { p.row_coef = nullptr; p.col_c = nullptr; }
     if (p.ln_partial) {
         if constexpr (NI == 4) launch_pp_fold<T, NT, MI, 4, 2>(p, stream);
@@ -452,11 +452,11 @@ bool gemm_ln_fold_ok(int prec, const GemmParams& p_in) {
     if (splits != 1) return false;
     if (p.ln_partial) {
         // producer: fp32 stream + residual, planes of the new rows, whole 64-column blocks, 256-column tiles
-        if (ni != 4 || p.N % 64 || p.N > 1024 || !p.out_f32 || !p.residual || !p.out_p || !p.ln_rowps || p.act || p.mode || p.row_len ||
-            p.row_coef)
-            return false;
+        if (ni != 4 || p.N % 64 || p.N > 1024 || !p.out_p || !p.ln_rowps || p.act || p.mode || p.row_len || p.row_coef) return false;
+        // the stream: fp32 rows in and out, or (two planes) the planes themselves as the residual and fp32 out only on request
+        if (p.ln_res_planes ? NT != 2 : (!p.out_f32 || !p.residual)) return false;
         if (NT == 2 && (p.out_plane != PLANE_IL || p.ldp % 32)) return false;
-        if (p.ldp % 8 || ((uintptr_t)p.out_p & 15) || ((uintptr_t)p.ln_partial & 7) || ((uintptr_t)p.ln_rowps & 7)) return false;
+        if (p.ldp % 8 || ((uintptr_t)p.out_p & 15) || ((uintptr_t)p.ln_partial & 7) || ((uintptr_t)p.ln_rowps & 15)) return false;
     }
     if (p.row_coef) {
         if (!p.col_c || ((uintptr_t)p.col_c & 15) || ((uintptr_t)p.row_coef & 7) || p.residual || p.row_len) return false;

@@ -931,7 +931,7 @@ __device__ __forceinline__ float ln_plane_scale(float rstd) {
 template <typename T, int NT>
 __global__ __launch_bounds__(256) void ln_rowprep_kernel(const float* __restrict__ x, int64_t ldx, int64_t M, int D, float eps,
                                                          T* __restrict__ out_p, int64_t out_plane, int64_t ldp,
-                                                         float2* __restrict__ rowps, float2* __restrict__ coef) {
+                                                         float4* __restrict__ rowps, float2* __restrict__ coef) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -959,7 +959,7 @@ __global__ __launch_bounds__(256) void ln_rowprep_kernel(const float* __restrict
     const float rs = 1.0f / sqrtf(wave_sum(q) * invD + eps);
     const float sc = ln_plane_scale(rs);
     if (lane == 0) {
-        rowps[row] = make_float2(mu, sc);
+        rowps[row] = make_float4(mu, sc, mu, sc);
         coef[row] = make_float2(rs / sc, 0.f);
     }
 #pragma unroll
@@ -985,7 +985,7 @@ __global__ __launch_bounds__(256) void ln_rowprep_kernel(const float* __restrict
 
 // one thread per row: Chan's pairwise update over the row's 64-column blocks, in ascending order
 __global__ __launch_bounds__(256) void ln_finalize_kernel(const float2* __restrict__ partial, int blocks, int64_t M, float eps,
-                                                          float2* __restrict__ rowps, float2* __restrict__ coef) {
+                                                          float4* __restrict__ rowps, float2* __restrict__ coef) {
     const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (row >= M) return;
     const float2* pr = partial + row * blocks;
@@ -1007,9 +1007,9 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float2* __restri
             m2 += fmaf(64.0f * d, d, b[j].y);
         }
     const float rs = 1.0f / sqrtf(m2 * invD + eps);
-    const float2 ps = rowps[row];
-    coef[row] = make_float2(rs / ps.y, -rs * m1);
-    rowps[row] = make_float2(ps.x + m1, ln_plane_scale(rs));
+    const float4 ps = rowps[row];  // the producer wrote the planes under (z, w): the statistics are those of x - z
+    coef[row] = make_float2(rs / ps.w, -rs * m1);
+    rowps[row] = make_float4(ps.z, ps.w, ps.z + m1, ln_plane_scale(rs));
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -1657,7 +1657,7 @@ void launch_rownorm(int prec, const float* x, int64_t ldx, int64_t M, int D, con
 }
 
 void launch_ln_rowprep(int prec, const float* x, int64_t ldx, int64_t M, int D, float eps, void* out_p, int64_t out_plane, int64_t ldp,
-                       float2* rowps, float2* coef, hipStream_t s) {
+                       float4* rowps, float2* coef, hipStream_t s) {
     dim3 grid((unsigned)((M + 3) / 4));
     switch (prec) {
         case PREC_BF16: hipLaunchKernelGGL((ln_rowprep_kernel<bf16, 1>), grid, dim3(256), 0, s, x, ldx, M, D, eps, (bf16*)out_p, out_plane, ldp, rowps, coef); break;
@@ -1667,7 +1667,7 @@ void launch_ln_rowprep(int prec, const float* x, int64_t ldx, int64_t M, int D, 
     }
 }
 
-void launch_ln_finalize(const float2* partial, int blocks, int64_t M, float eps, float2* rowps, float2* coef, hipStream_t s) {
+void launch_ln_finalize(const float2* partial, int blocks, int64_t M, float eps, float4* rowps, float2* coef, hipStream_t s) {
     hipLaunchKernelGGL(ln_finalize_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, partial, blocks, M, eps, rowps, coef);
 }
 
