@@ -520,6 +520,9 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
         tm.m[tensors[i].name] = &tensors[i];
         max_numel = std::max(max_numel, tensors[i].numel);
     }
+    // (the fused, LayerNorm-folded Q / K / V matrix is packed from one host buffer of 3 hidden^2 floats: larger than any single
+    // tensor when ffn < 3 hidden)
+    max_numel = std::max<int64_t>(max_numel, (int64_t)3 * cfg->hidden * cfg->hidden);
     float* staging = nullptr;
     if (hipMalloc(&staging, (size_t)max_numel * 4 + 16) != hipSuccess) { h->err = "staging allocation failed"; return bail(AMX_ENOMEM); }
     struct StagingGuard {

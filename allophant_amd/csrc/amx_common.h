@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #ifdef AMX_DEVELOPER
 #include <cstdlib>
 #endif
@@ -137,6 +138,24 @@ __device__ __forceinline__ void split16x2(f32x2 y, typename Vec2<T>::type& hi, t
         asm volatile("" : "+v"(hi));
         const f32x2 back = {(float)hi[0], (float)hi[1]};
         lo = __builtin_convertvector(y - back, V2);
+    }
+}
+
+// low plane of a split pair: lo = f16(x - hi).  x - float(hi) is exact in fp32 (hi is x rounded to 11 bits), so the fused form
+// fma(float(hi), -1, x) rounded once to f16 is the same value -- and one v_fma_mixlo / mixhi_f16 per value instead of a convert
+// back, a subtract and a share of a packed convert.  (bf16 has no mixed-precision fma: the three-step form.)
+template <typename T>
+__device__ __forceinline__ typename Vec2<T>::type residual2(f32x2 x, typename Vec2<T>::type hi) {
+    typedef typename Vec2<T>::type V2;
+    if constexpr (std::is_same<T, f16>::value) {
+        const unsigned h = __builtin_bit_cast(unsigned, hi);
+        unsigned lo;
+        asm("v_fma_mixlo_f16 %0, %1, %3, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(h), "v"(x[0]), "s"(-1.0f));
+        asm("v_fma_mixhi_f16 %0, %1, %3, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(h), "v"(x[1]), "s"(-1.0f));
+        return __builtin_bit_cast(V2, lo);
+    } else {
+        const f32x2 back = {(float)hi[0], (float)hi[1]};
+        return __builtin_convertvector(x - back, V2);
     }
 }
 

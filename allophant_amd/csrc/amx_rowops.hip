@@ -997,18 +997,22 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float2* __restri
             b[j] = pr[j];
             s1 += b[j].x;
         }
+    // the producer wrote the planes under (pivot z, scale w) and formed the statistics of u = (x - z) * w: w is a power of two, so
+    // the sums are those of x - z times w (times w^2) exactly
+    const float4 ps = rowps[row];
+    const float inv_w = __uint_as_float(0x7F000000u - __float_as_uint(ps.w));
     const float invD = 1.0f / (float)(blocks * 64);
-    const float m1 = s1 * invD;  // mean of x - pivot
+    const float mu = s1 * invD;  // mean of u
     float m2 = 0.f;
 #pragma unroll
     for (int j = 0; j < 16; ++j)
         if (j < blocks) {
-            const float d = b[j].x * (1.0f / 64.0f) - m1;
+            const float d = b[j].x * (1.0f / 64.0f) - mu;
             m2 += fmaf(64.0f * d, d, b[j].y);
         }
-    const float rs = 1.0f / sqrtf(m2 * invD + eps);
-    const float4 ps = rowps[row];  // the producer wrote the planes under (z, w): the statistics are those of x - z
-    coef[row] = make_float2(rs / ps.w, -rs * m1);
+    const float m1 = mu * inv_w;  // mean of x - pivot
+    const float rs = 1.0f / sqrtf(m2 * invD * inv_w * inv_w + eps);
+    coef[row] = make_float2(rs * inv_w, -rs * m1);
     rowps[row] = make_float4(ps.z, ps.w, ps.z + m1, ln_plane_scale(rs));
 }
 
