@@ -127,20 +127,6 @@ __device__ __forceinline__ void split16(float x, T& hi, T& lo) {
     }
 }
 
-// the same for two values at once: packed converts (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32) and one v_pk_add_f32 for the
-// residuals; `y` and `hi` are pinned to one register (pair) each like in split16
-template <typename T, int NT>
-__device__ __forceinline__ void split16x2(f32x2 y, typename Vec2<T>::type& hi, typename Vec2<T>::type& lo) {
-    typedef typename Vec2<T>::type V2;
-    if (NT > 1) asm volatile("" : "+v"(y));
-    hi = __builtin_convertvector(y, V2);
-    if (NT > 1) {
-        asm volatile("" : "+v"(hi));
-        const f32x2 back = {(float)hi[0], (float)hi[1]};
-        lo = __builtin_convertvector(y - back, V2);
-    }
-}
-
 // low plane of a split pair: lo = f16(x - hi).  x - float(hi) is exact in fp32 (hi is x rounded to 11 bits), so the fused form
 // fma(float(hi), -1, x) rounded once to f16 is the same value -- and one v_fma_mixlo / mixhi_f16 per value instead of a convert
 // back, a subtract and a share of a packed convert.  (bf16 has no mixed-precision fma: the three-step form.)
@@ -156,6 +142,21 @@ __device__ __forceinline__ typename Vec2<T>::type residual2(f32x2 x, typename Ve
     } else {
         const f32x2 back = {(float)hi[0], (float)hi[1]};
         return __builtin_convertvector(x - back, V2);
+    }
+}
+
+// the same for two values at once: packed converts (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32) and one v_pk_add_f32 for the
+// residuals; `y` and `hi` are pinned to one register (pair) each like in split16
+template <typename T, int NT>
+__device__ __forceinline__ void split16x2(f32x2 y, typename Vec2<T>::type& hi, typename Vec2<T>::type& lo) {
+    typedef typename Vec2<T>::type V2;
+    if (NT > 1) asm volatile("" : "+v"(y));
+    hi = __builtin_convertvector(y, V2);
+    if (NT > 1) {
+        asm volatile("" : "+v"(hi));
+        // (fp16: one v_fma_mixlo / mixhi_f16 per value -- residual2 -- instead of two converts back, a packed subtract and a packed
+        // convert: the same bits, 3 instead of 5 instructions per pair in every epilogue that writes planes; round 6)
+        lo = residual2<T>(y, hi);
     }
 }
 

@@ -47,12 +47,13 @@ MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/f16 MFMA peak, /opt/skills/guides/MI355X
 HBM_PEAK_GBS = 8000.0
 MEASURED_MFMA_CEILING_TFLOPS = 2100.0  # 16x16x32 f16, two waves per SIMD (profiles/r02_mfma_only_ceiling.log)
 CONV0_PATTERN_STORE_GBS = 5660.0  # conv0's own store pattern without its arithmetic (tools/store_bw_probe.hip, profiles/r03_store_bw.log)
-TRAFFIC_FILES = ("r05_traffic.json", "r04_traffic.json", "r04b_traffic.json", "r03il_traffic.json", "r03_traffic.json", "r02_traffic.json")  # newest first; written by tools/collect_profiles.py
+TRAFFIC_FILES = ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r04b_traffic.json", "r03il_traffic.json", "r03_traffic.json", "r02_traffic.json")  # newest first; written by tools/collect_profiles.py
 
 
 # BASELINE.json configs this file can time on one GPU (config 3 = config 2 under --gpus N; config 1 is CPU plumbing):
 # (utterances, seconds, phones of the synthetic inventory, hierarchical graph)
 CONFIG_PRESETS = {
+    1: (1, 3.0, 64, "baseline"),  # the reference's CPU-runnable case on the device: baseline schema (one phoneme classifier, no composition)
     2: (32, 10.0, 27, False),   # multitask, 'es'-sized inventory -- the configuration `metric` is quoted on (default)
     4: (64, 5.0, 48, True),     # hierarchical: the phoneme head sees cat(OUTPUT, softmax(attribute logits)), ['es','it']-sized
     5: (8, 60.0, 200, False),   # long-form stress: 200-phone inventory (its stated fp16 single-plane mode: --also f16)
@@ -70,8 +71,10 @@ def build_encoder(name):
     return encoder
 
 
-def build_spec(hierarchical=False, encoder_name="xlsr"):
+def build_spec(hierarchical=False, encoder_name="xlsr", phones=64):
     encoder = build_encoder(encoder_name)
+    if hierarchical == "baseline":  # BASELINE config 1: `kgnlp/allophant-baseline` schema -- a single phoneme head Linear(hidden -> P + 1)
+        return S.baseline_spec(encoder, phonemes=phones)
     spec = S.hierarchical_spec(encoder, allophone_layer=True) if hierarchical else S.multitask_spec(encoder, allophone_layer=True)
     spec["shared_phones"] = 80
     return spec
@@ -116,7 +119,8 @@ def work_model(spec, n, length, planes):
     products.append((M, attr_cols, D, 1))
     phoneme = next(c for c in spec["classes"] if c["name"] == "phoneme")
     k_phoneme = synthetic.head_input_size(spec, phoneme)
-    products.append((M, spec["embedding_size"], (k_phoneme + 31) // 32 * 32, 1))  # K padded to the 32-element row blocks
+    # (baseline schema: the phoneme head is a plain classifier of P + 1 columns, no embedding composition)
+    products.append((M, spec["embedding_size"] or phoneme["size"] + 1, (k_phoneme + 31) // 32 * 32, 1))  # K padded to the 32-element row blocks
     pp = tile = 0
     pp_launches = 0
     pp_bytes = 0
@@ -183,7 +187,7 @@ def cpu_baseline(spec, state, tfi, audio, lengths):
     from oracle import allophant_oracle as O
 
     cores, logical = physical_cores()
-    offsets = synthetic.category_offsets(spec)
+    offsets = synthetic.category_offsets(spec) if spec.get("composition_categories") else None
     candidates = sorted({max(1, cores), max(1, cores // 2), max(1, cores // 4), min(8, max(1, cores))}, reverse=True)
     sweep = {}
     probe_a, probe_l = audio[:2].contiguous(), lengths[:2].contiguous()
@@ -320,7 +324,8 @@ def main():
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "bf16x3", "f16", "bf16"])
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIG_PRESETS),
                     help="BASELINE.json config to time on one GPU: 2 (default, the configuration `metric` is quoted on; config 3 "
-                         "under --gpus N), 4 (hierarchical, 64 x 5 s) or 5 (8 x 60 s, 200 phones)")
+                         "under --gpus N), 4 (hierarchical, 64 x 5 s), 5 (8 x 60 s, 200 phones) or 1 (baseline schema, 1 x 3 s: the "
+                         "reference's CPU-runnable case, here on the device)")
     ap.add_argument("--encoder", default="xlsr", choices=["xlsr", "w2v2-base", "w2v2-large"],
                     help="wav2vec 2.0 shape and variant: xlsr (default; `metric` is quoted on it) or the group-norm / post-LN family "
                          "(informational lines: other work per frame)")
@@ -380,12 +385,13 @@ def main():
     from allophant_amd import parallel
     from allophant_amd.estimator import Batch, Estimator
 
-    spec = build_spec(hierarchical=preset[3], encoder_name=args.encoder)
+    spec = build_spec(hierarchical=preset[3], encoder_name=args.encoder, phones=args.phones)
     state = synthetic.make_state_dict(spec, seed=0)
-    tfi = synthetic.make_inventory(spec, args.phones, seed=0)
+    tfi = synthetic.make_inventory(spec, args.phones, seed=0) if spec.get("embedding_size") else None
     length = int(args.seconds * 16000)
 
     graph_stats = {}
+    pass_stats = {}
 
     def measure(precision, steps, warmup, batch, timing_pass=True):
         """K timed steps (no per-kernel events: recording ~370 events costs 0.3-1.2 ms per step) bracketed by barrier +
@@ -427,6 +433,7 @@ def main():
             dist.all_reduce(t_tensor, op=dist.ReduceOp.MAX)
         elapsed = float(t_tensor.item())
         graph_stats[precision] = est.graph_info()  # (passes recorded into HIP graphs, passes replayed) up to the end of the timed region
+        pass_stats[precision] = est.pass_info()    # what the last timed pass did: LayerNorm fold, row layout, eager / recorded / replayed
         timing = None
         if timing_pass:
             # instrumented pass: same steps, HIP events on the launch stream around every kernel
@@ -563,7 +570,9 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         config_name = f"BASELINE config {args.config}" if world == 1 else f"BASELINE config 3 (config 2 sharded {n_local} utterances per GPU x {world}, RCCL gather of log-probs to rank 0)"
-        graph_name = ("hierarchical checkpoint schema (36 attribute heads; the composed phoneme head reads cat(OUTPUT, softmax of every "
+        graph_name = ("baseline checkpoint schema (one phoneme classifier Linear(hidden -> P + 1), no attribute heads, no composition"
+                      if preset[3] == "baseline" else
+                      "hierarchical checkpoint schema (36 attribute heads; the composed phoneme head reads cat(OUTPUT, softmax of every "
                       "attribute head)" if preset[3] else "multitask checkpoint schema (36 attribute heads + composed phoneme head")
         result = {
             "metric": "encoder frames/sec (whole node), 10s x 32 utterances @16kHz" if args.config == 2 and args.encoder == "xlsr" else
@@ -598,6 +607,9 @@ def main():
             # launch collapse (ABI 5): the timed steps replay ONE HIP graph of the ~185 launches of a pass
             "launch_collapse": {"graphs_recorded": graph_stats[args.precision][0], "passes_replayed": graph_stats[args.precision][1],
                                 "passes_issued": args.steps + args.warmup},
+            # amx_pass_info of the last timed pass: ln_fold 1 = the pre-LN layers ran without LayerNorm passes (folded into the
+            # products around them: `kernels.rownorm` is then the fold's row statistics + the first / final norm), packed rows, graph
+            "pass": pass_stats.get(args.precision),
         }
     # N > 1: the weak-scaling leg (config 2 on every GPU), reported beside the strong-scaling headline
     if world > 1 and not args.no_weak:
@@ -687,7 +699,7 @@ def main():
             }
     # N = 1: what a ragged batch gets (informational; `value` is the equal-length config above): the encoder layers run on the
     # valid frames only and the conv stack skips tiles that lie in padding, against the padded layout of the same batch
-    if world == 1 and not args.no_ragged:
+    if world == 1 and not args.no_ragged and n_global > 1:
         try:
             g = torch.Generator().manual_seed(9)
             r_lengths = torch.randint(int(0.2 * length), length + 1, (n_global,), generator=g)
@@ -740,7 +752,7 @@ def main():
 
                     n_check = 1
                     oracle_out, oracle_len = O.predict(audio[:1].contiguous(), lengths[:1].contiguous(), state, spec, tfi,
-                                                       synthetic.category_offsets(spec), True)
+                                                       synthetic.category_offsets(spec) if spec.get("composition_categories") else None, True)
                 est = Estimator(spec, state, device, args.precision)
                 pred = est.predict(local, tfi, True, _no_graph=args.no_graph)  # rank 0's shard starts at utterance 0 of the global batch
                 range_error = None

@@ -17,6 +17,7 @@ and a checkpoint whose activations really leave the fp16 range is refused loudly
 ``FloatingPointError``) while ``bf16x3`` (fp32 range) runs it.  Weights cannot leave the range: they are packed under
 per-tensor power-of-two scales (``amx_create``).
 """
+import ctypes as C
 import math
 import zlib
 
@@ -192,3 +193,69 @@ def test_activation_overflow_is_refused_not_silent(amd):
         est.predict(batch, tfi)
         est.check_finite()
         est.close()
+
+
+def test_range_report_names_the_pass_and_host_io_reports_at_once(amd):
+    """Round-5 advisor finding: an AMX_ERANGE report belonged to an unidentified earlier pass, and a host-I/O call (which returns
+    synchronised, its bad outputs already handed over) left the report to whatever call came next.  Passes of a handle are
+    numbered (``amx_pass_info``: AMX_PASS_INFO_ID), the report names the offending pass, and ``amx_forward(AMX_FLAG_HOST_IO)``
+    returns AMX_ERANGE itself."""
+    import ctypes as C
+    import re
+
+    import numpy as np
+
+    from allophant_amd import lib as L
+    from allophant_amd.estimator import _spec_to_structs
+
+    spec = S.multitask_spec(S.tiny_encoder(2), ["syllabic", "long"], embedding_size=16, train_phonemes=9, n_features=5)
+    state = synthetic.make_state_dict(spec, seed=8)
+    _scale(state, "feed_forward.intermediate_dense", +16)
+    _scale(state, "feed_forward.output_dense.weight", -16, biases=False)
+    tfi = synthetic.make_inventory(spec, 7, seed=1)
+    audio, lengths = synthetic.make_audio(2, 6000, seed=5)
+    batch = amd.Batch(audio.cuda(), lengths, torch.zeros(2, dtype=torch.long))
+    est = amd.Estimator(spec, state, "cuda:0", "f16x3")
+    est.predict(batch, tfi)
+    assert est.pass_info()["id"] == 1
+    torch.cuda.synchronize()
+    with pytest.raises(FloatingPointError) as info:
+        est.predict(batch, tfi)
+    found = re.search(r"pass #(\d+): (\d+)", str(info.value))
+    assert found and int(found.group(1)) == 1 and int(found.group(2)) > 0, str(info.value)
+    assert "would be #2" in str(info.value)   # nothing of the refused call was issued
+    est.close()
+
+    # the raw C ABI with host buffers: the call that produced the overflow returns AMX_ERANGE itself
+    lib = L.load()
+    cfg, descs = _spec_to_structs(spec, "f16x3")
+    arrays = {k: np.ascontiguousarray(v.detach().cpu().numpy(), dtype=np.float32) for k, v in state.items()}
+    tensors = (L.AmxTensor * len(arrays))()
+    for i, (name, a) in enumerate(arrays.items()):
+        tensors[i].name = name.encode()
+        tensors[i].data = a.ctypes.data_as(C.POINTER(C.c_float))
+        tensors[i].numel = a.size
+    handle = C.c_void_p()
+    L.check(lib, None, lib.amx_create(C.byref(handle), 0, C.byref(cfg), descs, len(descs), tensors, len(arrays)))
+    try:
+        tfi_np = np.ascontiguousarray(tfi.numpy(), dtype=np.int64)
+        offsets = np.cumsum([1] + list(spec["composition_categories"]), dtype=np.int64)[:-1].copy()
+        L.check(lib, handle, lib.amx_set_inventory(handle, tfi_np.ctypes.data_as(C.POINTER(C.c_int64)), tfi_np.shape[0], tfi_np.shape[1],
+                                                   offsets.ctypes.data_as(C.POINTER(C.c_int64)), None))
+        audio_np = np.ascontiguousarray(audio.numpy(), dtype=np.float32)
+        len_np = np.ascontiguousarray(lengths.numpy(), dtype=np.int64)
+        n, l = audio_np.shape
+        n_out, t, total = C.c_int(), C.c_int64(), C.c_int64()
+        L.check(lib, handle, lib.amx_output_layout(handle, n, l, None, C.byref(n_out), C.byref(t), C.byref(total)))
+        out = np.empty(total.value, dtype=np.float32)
+        out_len = np.empty(n, dtype=np.int64)
+        code = lib.amx_forward(handle, C.c_void_p(audio_np.ctypes.data), len_np.ctypes.data_as(C.POINTER(C.c_int64)), n, l,
+                               C.c_void_p(out.ctypes.data), out_len.ctypes.data_as(C.POINTER(C.c_int64)), L.FLAG_HOST_IO, None)
+        assert code == L.AMX_ERANGE
+        assert b"pass #1" in lib.amx_last_error(handle)
+        # the report was consumed: the next call goes through (and reports its own pass again)
+        code = lib.amx_forward(handle, C.c_void_p(audio_np.ctypes.data), len_np.ctypes.data_as(C.POINTER(C.c_int64)), n, l,
+                               C.c_void_p(out.ctypes.data), out_len.ctypes.data_as(C.POINTER(C.c_int64)), L.FLAG_HOST_IO, None)
+        assert code == L.AMX_ERANGE and b"pass #2" in lib.amx_last_error(handle)
+    finally:
+        lib.amx_destroy(handle)
