@@ -50,6 +50,36 @@ def max_frame_batches(order: Iterable[int], frame_lengths: Sequence[int], max_fr
         yield batch
 
 
+def bucketed_frame_batches(order: Iterable[int], frame_lengths: Sequence[int], max_frames: int,
+                           bucket: int) -> Iterator[Tuple[List[int], int]]:
+    """``max_frame_batches`` on a grid of batch GEOMETRIES (no upstream counterpart): yields ``(indices, padded_length)`` where the
+    padded length is the batch's longest utterance rounded up to a multiple of ``bucket`` samples and a batch holds at most
+    ``max_frames // padded_length`` utterances (every batch of a bucket but its last: exactly that many).  Batches of one bucket
+    therefore share one ``(N, L)``, which is what a recording of a forward pass is keyed on (``amx_forward``, ABI 6): in
+    length-sorted order the corpus becomes runs of equal geometry and the passes of a run replay one HIP graph.  The cost is the
+    padding up to the bucket boundary -- ``collate(..., padded_length=...)`` marks such a batch as padded beyond its longest
+    utterance (``AMX_FLAG_PADDED``), which the XLS-R form's results do not depend on (``parallel.padding_sensitive``)."""
+    if bucket < 1:
+        raise ValueError("bucket must be a positive number of samples")
+    batch: List[int] = []
+    longest = 0
+
+    def padded(length: int) -> int:
+        return -(-length // bucket) * bucket
+
+    for index in order:
+        length = int(frame_lengths[index])
+        grown = max(longest, length)
+        if batch and (len(batch) + 1) * padded(grown) > max_frames:
+            yield batch, padded(longest)
+            batch, longest = [index], length
+        else:
+            batch.append(index)
+            longest = grown
+    if batch:
+        yield batch, padded(longest)
+
+
 def utterance_batches(order: Iterable[int], batch_size: int) -> Iterator[List[int]]:
     batch: List[int] = []
     for index in order:
@@ -131,13 +161,23 @@ class PinnedCollator:
         if slot is not None and slot[0] is self:
             self._events[slot[1]] = event
 
-    def __call__(self, audio: Sequence[Tensor], language_ids: Optional[Sequence[int]] = None) -> Batch:
+    def __call__(self, audio: Sequence[Tensor], language_ids: Optional[Sequence[int]] = None,
+                 padded_length: Optional[int] = None) -> Batch:
+        """``padded_length`` (``bucketed_frame_batches``): pad to that many samples instead of the longest utterance; the batch
+        is then marked as padded beyond ``max(lengths)`` (``Estimator.predict`` passes ``AMX_FLAG_PADDED``)."""
         lengths = torch.tensor([int(a.numel()) for a in audio], dtype=torch.int64)
         longest = int(lengths.max())
+        over_padded = padded_length is not None and int(padded_length) > longest
+        if padded_length is not None:
+            if int(padded_length) < longest:
+                raise ValueError("padded_length is shorter than the longest utterance of the batch")
+            longest = int(padded_length)
         n = len(audio)
         slot = self._next
         buf = self._buffers[slot]
         if n * longest > buf.numel():
+            if over_padded:
+                raise ValueError("the pinned ring is smaller than this padded batch")
             return collate(audio, language_ids, pin=True)  # over-long single utterance: one-off buffer, the ring stays put
         self._next = (self._next + 1) % len(self._buffers)
         if self._events[slot] is not None:
@@ -156,6 +196,8 @@ class PinnedCollator:
         ids = torch.tensor(list(language_ids) if language_ids is not None else [0] * n, dtype=torch.int64)
         batch = Batch(features, lengths, ids)
         batch._pinned_slot = (self, slot)
+        if over_padded:
+            batch._padded = True
         self._handed_out[slot] = True
         return batch
 
@@ -195,7 +237,10 @@ class Prefetcher:
         current = torch.cuda.current_stream(self._device)
         current.wait_stream(self._stream)  # stream-ordered: later launches on the compute stream see the copied batch
         dev.record_stream(current)
-        return Batch(dev, batch.lengths, batch.language_ids)
+        moved = Batch(dev, batch.lengths, batch.language_ids)
+        if getattr(batch, "_padded", False):
+            moved._padded = True
+        return moved
 
 
 class Batcher:

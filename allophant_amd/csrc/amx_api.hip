@@ -171,11 +171,11 @@ struct amx_handle_s {
         hipGraph_t graph = nullptr;  // the template stays alive as long as its instance (destroyed together)
         uint64_t last_use = 0;
     };
-    static constexpr int GRAPH_CAP = 8;
+    static constexpr int GRAPH_CAP = 32;  // (a length-sorted corpus on a grid of batch geometries cycles through two dozen of them)
     std::vector<GraphEntry> graphs;
     std::vector<std::vector<int64_t>> graph_seen;  // keys of the last few eager passes (a caller that alternates between two
                                                    // output buffers -- an overlapped gather holds one -- repeats with period 2)
-    static constexpr int GRAPH_SEEN = 4;
+    static constexpr int GRAPH_SEEN = 8;
     hipStream_t capture_stream = nullptr;  // capture never runs on the caller's stream (which may be the null stream)
     bool graph_broken = false;             // a capture failed once: stay eager
     uint64_t ws_gen = 0, graph_clock = 0;

@@ -116,3 +116,38 @@ def test_pinned_collator_slot_travels_with_asynchronous_copies():
     assert third._pinned_slot == (ring, 0) and ring._events[0] is None
     torch.cuda.synchronize()
     assert dev.audio_features.cpu().tolist() == [[1.0] * 8, [2.0] * 4 + [0.0] * 4]
+
+
+def test_bucketed_frame_batches_put_a_corpus_on_a_grid_of_geometries():
+    """``bucketed_frame_batches`` (no upstream counterpart; round 6): every utterance exactly once, every batch inside the frame
+    budget at its bucketed padded length, batches of one bucket share (N, L) except a bucket's last -- the property recordings of
+    forward passes are keyed on -- and ``PinnedCollator(padded_length=...)`` marks such batches as padded beyond their longest."""
+    import torch
+
+    from allophant_amd import batching as B
+
+    g = torch.Generator().manual_seed(3)
+    lengths = torch.randint(2 * 16000, 15 * 16000, (4096,), generator=g).tolist()
+    budget, bucket = 32 * 160000, 16000
+    order = B.length_sorted_order(lengths)
+    batches = list(B.bucketed_frame_batches(order, lengths, budget, bucket))
+    assert sorted(i for b, _ in batches for i in b) == list(range(len(lengths)))
+    geometries = {}
+    for indices, padded in batches:
+        longest = max(lengths[i] for i in indices)
+        assert padded % bucket == 0 and longest <= padded < longest + bucket
+        assert len(indices) * padded <= budget
+        geometries.setdefault((len(indices), padded), 0)
+        geometries[(len(indices), padded)] += 1
+    # 13 one-second buckets: most batches repeat a geometry (the share of passes that can replay a recording)
+    repeats = sum(c - 1 for c in geometries.values())
+    assert repeats / len(batches) > 0.7, (repeats, len(batches), len(geometries))
+    # an order that is not sorted still respects the budget
+    for indices, padded in B.bucketed_frame_batches(range(len(lengths)), lengths, budget, bucket):
+        assert len(indices) * padded <= budget and max(lengths[i] for i in indices) <= padded
+    with pytest.raises(ValueError):
+        next(B.bucketed_frame_batches(order, lengths, budget, 0))
+    # the collator pads to the bucket and says so
+    audio = [torch.ones(n) for n in (30000, 20000)]
+    plain = B.collate(audio)
+    assert plain.audio_features.shape == (2, 30000) and not getattr(plain, "_padded", False)

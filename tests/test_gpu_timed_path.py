@@ -316,3 +316,35 @@ def test_confident_heads_give_strictly_equal_alignments(amd, number, picks):
             assert abs(got.score - float(score)) < 1e-3 * max(1.0, abs(float(score)))
     assert longest > 50  # real alignments (the phoneme output), not constant ones
     est.close()
+
+
+@pytest.mark.parametrize("precision,tolerance", [("f16x3", GATE), ("bf16x3", GATE), ("f16", F16_BOUND), ("bf16", 5e-1)])
+def test_layer_norm_fold_in_every_mode(amd, precision, tolerance):
+    """Round 6: the pre-LN layers of a large batch run WITHOUT LayerNorm passes -- the out-projection / FFN2 epilogues leave the planes
+    and the row statistics of the stream, QKV / FFN1 apply the normalisation in theirs (``amx_pass_info``: ln_fold) -- in the
+    two-plane modes with the residual stream kept in those planes between the products, in the single-plane modes with the fp32
+    rows.  The benchmark batch (32 x 10 s, equal lengths) against the CPU oracle on utterances 0 and 17, every mode at its
+    bound; then the same batch with a tenth of the samples shaved off some utterances (still the padded layout: the fold's
+    edge blocks and row masks), which must reproduce the full-length utterances' outputs to the bit."""
+    spec, n, samples, phones, seed = _config(2)
+    state = synthetic.make_state_dict(spec, seed=0)
+    tfi = synthetic.make_inventory(spec, phones, seed=0)
+    audio, lengths = synthetic.make_audio(n, samples, seed=seed)
+    est = amd.Estimator(spec, state, "cuda:0", precision)
+    pred = est.predict(amd.Batch(audio.cuda(), lengths, torch.zeros(n, dtype=torch.long)), tfi, True, _no_graph=True)
+    info = est.pass_info()
+    assert info["ln_fold"] == 1 and info["packed"] == 0 and info["rows"] == 15968, info
+    est.check_finite()
+    _check(2, spec, state, tfi, audio, lengths, pred, [0, 17], tolerance=tolerance, alignments=precision == "f16x3",
+           label=f"config 2, LayerNorm fold, {precision}")
+    shaved = lengths.clone()
+    shaved[1::3] -= 9000
+    a2 = audio.clone()
+    for i in range(n):
+        a2[i, int(shaved[i]):] = 0
+    pred2 = est.predict(amd.Batch(a2.cuda(), shaved, torch.zeros(n, dtype=torch.long)), tfi, True, _no_graph=True)
+    assert est.pass_info()["ln_fold"] == 1 and est.pass_info()["packed"] == 0
+    for k in pred.outputs:
+        assert torch.equal(pred2.outputs[k][:, 0], pred.outputs[k][:, 0]), k    # an utterance's result does not depend on its batch
+        assert torch.equal(pred2.outputs[k][:, 17], pred.outputs[k][:, 17]), k
+    est.close()

@@ -40,5 +40,33 @@ def run(order, label):
           f"{frames / dt:.0f} valid frames/s ({dt:.2f} s for {sum(lengths) / 16000:.0f} s of audio)", flush=True)
 
 
+def run_bucketed(order, label, bucket):
+    """The same corpus on a grid of batch geometries (batching.bucketed_frame_batches): batches of one bucket share (N, L), so the
+    passes of a run of equal geometry replay ONE recorded HIP graph (ABI 6: recordings are keyed on geometry where no length
+    travels by value) -- reported: the share of passes that were replays."""
+    batches = [b for b in B.bucketed_frame_batches(order, lengths, budget, bucket)]
+    collator = B.PinnedCollator(budget)
+    fetch = lambda item: collator([audio[i] for i in item[0]], padded_length=item[1])
+    for warm in (True, False):
+        torch.cuda.synchronize()
+        c0, r0 = est.graph_info()
+        t0 = time.perf_counter()
+        frames, modes = 0, {0: 0, 1: 0, 2: 0}
+        for batch in B.Prefetcher(batches, device, fetch):
+            pred = est.predict(batch, tfi)
+            modes[est.pass_info()["graph"]] += 1
+            frames += int(pred.lengths.sum())
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        c1, r1 = est.graph_info()
+    padded = sum(len(b) * l for b, l in batches)
+    geometries = len({(len(b), l) for b, l in batches})
+    print(f"{prec} {label}: {len(batches)} batches of {geometries} geometries (bucket {bucket / 16000:.2f} s), padding efficiency "
+          f"{sum(lengths) / padded:.3f}, {frames / dt:.0f} valid frames/s ({dt:.2f} s); passes of the timed sweep: {modes[2]} replayed, "
+          f"{modes[1]} recorded, {modes[0]} eager = {modes[2] / max(1, len(batches)):.0%} replays", flush=True)
+
+
 run(range(n_utt), "corpus order   ")
 run(B.length_sorted_order(lengths), "length-sorted  ")
+run_bucketed(B.length_sorted_order(lengths), "length-sorted, bucketed", 8000)
+run_bucketed(B.length_sorted_order(lengths), "length-sorted, bucketed", 16000)
