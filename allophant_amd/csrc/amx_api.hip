@@ -1252,20 +1252,132 @@ static int range_record(amx_handle h, bool cont, hipStream_t s) {
     return AMX_OK;
 }
 
-extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* lengths, int N, int64_t L, float* out,
-                           int64_t* out_lengths, uint32_t flags, void* stream_) {
-    if (!h) return AMX_EINVAL;
-    if (!audio || !lengths || !out) return fail(h, AMX_EINVAL, "null buffer");
-    HIPCHK(h, hipSetDevice(h->device));
-    hipStream_t s = (hipStream_t)stream_;
+
+namespace {
+
+// split-K workspace (fp32 partial slabs of products too small to fill the chip; see launch_gemm): the partials of one product never
+// exceed CUs x 256 x 256 floats
+constexpr size_t SPLITK_BYTES = (size_t)72 << 20;
+
+// Everything amx_forward decides before it launches anything -- the PLAN of a pass: geometry, row layout, which optional forms the
+// pass takes (packed rows, skipped conv tiles, the LayerNorm fold, the stream kept in planes), every buffer, the products of an
+// encoder layer.  A plain value: plan_pass() fills it (and is the only place that may allocate, upload or synchronise),
+// enqueue_pass() reads it and issues nothing but kernels -- eagerly on the caller's stream, or once on the capture stream when
+// the pass is recorded into a HIP graph.  (Round 6: until then "plan + enqueue" was a lambda inside one 800-line function.)
+struct PassPlan {
+    amx_handle h = nullptr;
+    // the call
+    uint32_t flags = 0;
+    int N = 0;
+    int64_t L = 0;
+    const float* d_audio = nullptr;
+    float* d_out = nullptr;
+    int64_t total = 0;
+    // model shorthands
+    int NT = 2, prec = 0, C = 0, D = 0, F = 0, H = 0, dh = 64, dhp = 64, E = 0, Eld = 0, cg = 0;
+    // geometry
+    int64_t Ts[AMX_MAX_CONV + 1] = {};
+    int T = 0, Tp = 0, TpTot = 0, Tpad = 0;
+    int64_t M = 0, Mp = 0, Mrows = 0, Mh = 0, rows1 = 0, rows2 = 0, xp_plane = 0, qk_plane = 0;
+    size_t qkv_bytes = 0;
+    // the forms the pass takes
+    bool keep = false, masked = true, stable = true, blanks = true;
+    bool packed = false, packed_early = false, ragged = false, window_ok = false, needs_qkv_zero = false;
+    bool fold = false, stream_in_planes = false;
+    // buffers (workspace of the handle: valid until a later plan grows one of them)
+    void *d_len = nullptr, *d_frames = nullptr, *d_rowoff = nullptr, *d_partial = nullptr, *d_stats = nullptr, *actA = nullptr, *actB = nullptr,
+         *preln = nullptr, *hbuf = nullptr, *xp = nullptr, *hg = nullptr, *qb = nullptr, *kb = nullptr, *vtb = nullptr, *ao = nullptr, *ff = nullptr,
+         *hfin = nullptr, *logits = nullptr, *hpk = nullptr, *splitk = nullptr, *gn_partial = nullptr, *gn_scale = nullptr, *gn_shift = nullptr,
+         *ebuf = nullptr, *cat = nullptr, *tl_x = nullptr, *tl_p = nullptr, *tl_qkv = nullptr, *ln_rowps = nullptr, *ln_coef = nullptr,
+         *ln_partial = nullptr;
+    const int* d_frames_enc = nullptr;
+    int* d_tiles = nullptr;
+    size_t tile_first[AMX_MAX_CONV + 1] = {};
+    std::vector<float*> saved;   // per layer: where hidden state l is published (null: nobody reads it)
+    float* conv_dbg = nullptr;
+    float* hfin_rows = nullptr;
+    float* stream = nullptr;     // the residual stream of the layers [Mrows, D]
+    // host copies the tail of amx_forward keeps for amx_debug_fetch (packed_early only)
+    std::vector<int> rowoff_host, frames_host;
+
+    int64_t plane(int64_t separate) const { return h->il ? PLANE_IL : std::max<int64_t>(separate, 64); }  // pln(h, .)
+    GemmParams with_ws(GemmParams g) const {
+        g.splitk_ws = (float*)splitk;
+        g.splitk_ws_elems = splitk ? (int64_t)(SPLITK_BYTES / 4) : 0;
+        return g;
+    }
+    // ---- the products of an encoder layer ----
+    GemmParams qkv_params(const Layer& ly) const {
+        GemmParams g{};
+        g.A = xp; g.a_plane = xp_plane; g.lda = D; g.rows_per_batch = Mrows;
+        g.W = ly.wqkv; g.w_plane = plane((int64_t)3 * D * D); g.ldw = D;
+        g.M = (int)Mrows; g.N = 3 * D; g.K = D;
+        g.scale = ly.r_qkv; g.bias = ly.bqkv;
+        g.mode = 1; g.q = qb; g.k = kb; g.v = vtb;
+        g.qk_plane = qk_plane;
+        // packed rows: one "utterance" of Mp rows, so the scatter writes row m of head hh to [hh][m][:]
+        g.T = packed ? (int)std::max<int64_t>(Mp, 8) : T; g.Tp = packed ? TpTot : Tp; g.H = H; g.dh = dh; g.dhp = dhp;
+        return with_ws(g);
+    }
+    GemmParams oproj_params(const Layer& ly) const {
+        GemmParams g{};
+        g.A = ao; g.a_plane = xp_plane; g.lda = D; g.rows_per_batch = Mrows;
+        g.W = ly.wo; g.w_plane = plane((int64_t)D * D); g.ldw = D;
+        g.M = (int)Mrows; g.N = D; g.K = D;
+        g.scale = ly.r_o; g.bias = ly.bo;
+        g.residual = stream; g.ldr = D; g.out_f32 = stream; g.ldo = D;
+        return with_ws(g);
+    }
+    GemmParams ffn1_params(const Layer& ly) const {
+        GemmParams g{};
+        g.A = xp; g.a_plane = xp_plane; g.lda = D; g.rows_per_batch = Mrows;
+        g.W = ly.w1; g.w_plane = plane((int64_t)F * D); g.ldw = D;
+        g.M = (int)Mrows; g.N = F; g.K = D;
+        g.scale = ly.r_1; g.bias = ly.b1; g.act = 1;
+        g.out_p = ff; g.out_plane = plane(Mrows * F); g.ldp = F;
+        return with_ws(g);
+    }
+    GemmParams ffn2_params(const Layer& ly) const {
+        GemmParams g{};
+        g.A = ff; g.a_plane = plane(Mrows * F); g.lda = F; g.rows_per_batch = Mrows;
+        g.W = ly.w2; g.w_plane = plane((int64_t)D * F); g.ldw = F;
+        g.M = (int)Mrows; g.N = D; g.K = F;
+        g.scale = ly.r_2; g.bias = ly.b2;
+        g.residual = stream; g.ldr = D; g.out_f32 = stream; g.ldo = D;
+        return with_ws(g);
+    }
+    // LayerNorm fold (pre-LN layers; GemmParams.ln_partial / row_coef): the out-projection and FFN2 leave the planes and the row
+    // statistics of the stream they have just updated, QKV and FFN1 apply the normalisation in their epilogues -- no LayerNorm
+    // pass between the products of a layer.  Only where all four products run on the ping-pong kernel in one piece (batches
+    // from a few thousand frames: every benchmark configuration); short batches keep the row pass -- with (1, 0) as its affine
+    // part, since the weights hold gamma and beta either way -- fused with the split-K fix-up as before.
+    GemmParams as_consumer(GemmParams g, const float* col_c) const {
+        g.row_coef = (const float2*)ln_coef; g.col_c = col_c;
+        return g;
+    }
+    // Two-plane modes (stream_in_planes): between the products of a layer the stream lives in its planes only -- a producer reads its
+    // residual from them and writes fp32 rows only where something reads those (`f32`: a published hidden state, the last layer:
+    // the final LayerNorm and the unpacking read fp32)
+    GemmParams as_producer(GemmParams g, bool f32 = true) const {
+        g.ln_partial = (float2*)ln_partial; g.ln_rowps = (const float4*)ln_rowps;
+        g.out_p = xp; g.out_plane = xp_plane; g.ldp = D;
+        if (stream_in_planes) {
+            g.ln_res_planes = 1;
+            g.residual = nullptr;
+            if (!f32) g.out_f32 = nullptr;
+        }
+        return g;
+    }
+};
+
+}  // namespace
+
+// The plan region of a forward pass (see PassPlan): argument and geometry checks, pinned uploads of lengths / frame counts / row
+// offsets / tile lists, every workspace buffer (ws_get may allocate, free and synchronise), the concatenation recipes of dependent
+// classifiers, and the decisions that depend on the lengths.
+static int plan_pass(amx_handle h, const float* audio, const int64_t* lengths, int N, int64_t L, float* out, int64_t* out_lengths,
+                     uint32_t flags, hipStream_t s, PassPlan& P) {
     int rc;
-    // Safe by default: the reference computes in fp32 and cannot overflow (estimator.py:1035-1046); the fp16 planes can.  A
-    // pass that produced non-finite logits on valid frames is reported -- AMX_ERANGE -- by the first amx_forward /
-    // amx_synchronize issued after it has completed; nothing of THIS call has been enqueued when that happens.  No host
-    // synchronisation: only passes whose trailing event has completed are read.
-    if (!(flags & AMX_FLAG_NO_RANGE_CHECK) && (rc = range_poll(h, false))) return rc;
-    rc = compute_layout(h, N, L);
-    if (rc) return rc;
     const amx_config& c = h->cfg;
     const int NT = h->NT, prec = h->prec;
     const int C = c.conv_dim, D = c.hidden, F = c.ffn, H = c.heads;
@@ -1357,14 +1469,8 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     // split-K workspace (fp32 partial slabs of products too small to fill the chip; see launch_gemm): the partials of one
     // product never exceed CUs x 256 x 256 floats
     void* splitk = nullptr;
-    constexpr size_t SPLITK_BYTES = (size_t)72 << 20;
     static const bool no_splitk = dev_switch("AMX_NO_SPLITK");  // developer A/B switch
     if (!no_splitk) WS("splitk", SPLITK_BYTES, splitk);
-    auto run_gemm = [&](int precision, GemmParams& g, hipStream_t stream) {
-        g.splitk_ws = (float*)splitk;
-        g.splitk_ws_elems = splitk ? (int64_t)(SPLITK_BYTES / 4) : 0;
-        launch_gemm(precision, g, stream);
-    };
     WS("len", (size_t)N * 8, d_len);
     WS("frames", (size_t)N * 4, d_frames);
     void* d_rowoff;
@@ -1552,103 +1658,195 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         }
     }
     const bool needs_qkv_zero = !packed && (h->last_N != N || h->last_T != T || h->qkv_dirty);
-    // ---- the encoder layers' products (plan: the enqueue region only launches them) ----
     const int64_t Mrows = packed ? Mp : M;  // rows the layers work on
     const int64_t xp_plane = pln(h, Mrows * D);
     const int64_t qk_plane = packed ? (int64_t)H * TpTot * dhp : (int64_t)N * H * Tp * dhp;
     float* const stream = (float*)(packed ? hpk : hbuf);  // the residual stream of the layers [Mrows, D]
-    auto with_ws = [&](GemmParams g) {
-        g.splitk_ws = (float*)splitk;
-        g.splitk_ws_elems = splitk ? (int64_t)(SPLITK_BYTES / 4) : 0;
-        return g;
-    };
-    auto qkv_params = [&](const Layer& ly) {
-        GemmParams g{};
-        g.A = xp; g.a_plane = xp_plane; g.lda = D; g.rows_per_batch = Mrows;
-        g.W = ly.wqkv; g.w_plane = pln(h, (int64_t)3 * D * D); g.ldw = D;
-        g.M = (int)Mrows; g.N = 3 * D; g.K = D;
-        g.scale = ly.r_qkv; g.bias = ly.bqkv;
-        g.mode = 1; g.q = qb; g.k = kb; g.v = vtb;
-        g.qk_plane = qk_plane;
-        // packed rows: one "utterance" of Mp rows, so the scatter writes row m of head hh to [hh][m][:]
-        g.T = packed ? (int)std::max<int64_t>(Mp, 8) : T; g.Tp = packed ? TpTot : Tp; g.H = H; g.dh = dh; g.dhp = dhp;
-        return with_ws(g);
-    };
-    auto oproj_params = [&](const Layer& ly) {
-        GemmParams g{};
-        g.A = ao; g.a_plane = xp_plane; g.lda = D; g.rows_per_batch = Mrows;
-        g.W = ly.wo; g.w_plane = pln(h, (int64_t)D * D); g.ldw = D;
-        g.M = (int)Mrows; g.N = D; g.K = D;
-        g.scale = ly.r_o; g.bias = ly.bo;
-        g.residual = stream; g.ldr = D; g.out_f32 = stream; g.ldo = D;
-        return with_ws(g);
-    };
-    auto ffn1_params = [&](const Layer& ly) {
-        GemmParams g{};
-        g.A = xp; g.a_plane = xp_plane; g.lda = D; g.rows_per_batch = Mrows;
-        g.W = ly.w1; g.w_plane = pln(h, (int64_t)F * D); g.ldw = D;
-        g.M = (int)Mrows; g.N = F; g.K = D;
-        g.scale = ly.r_1; g.bias = ly.b1; g.act = 1;
-        g.out_p = ff; g.out_plane = pln(h, Mrows * F); g.ldp = F;
-        return with_ws(g);
-    };
-    auto ffn2_params = [&](const Layer& ly) {
-        GemmParams g{};
-        g.A = ff; g.a_plane = pln(h, Mrows * F); g.lda = F; g.rows_per_batch = Mrows;
-        g.W = ly.w2; g.w_plane = pln(h, (int64_t)D * F); g.ldw = F;
-        g.M = (int)Mrows; g.N = D; g.K = F;
-        g.scale = ly.r_2; g.bias = ly.b2;
-        g.residual = stream; g.ldr = D; g.out_f32 = stream; g.ldo = D;
-        return with_ws(g);
-    };
-    // LayerNorm fold (pre-LN layers; GemmParams.ln_partial / row_coef): the out-projection and FFN2 leave the planes and the row
-    // statistics of the stream they have just updated, QKV and FFN1 apply the normalisation in their epilogues -- no LayerNorm
-    // pass between the products of a layer.  Only where all four products run on the ping-pong kernel in one piece (batches
-    // from a few thousand frames: every benchmark configuration); short batches keep the row pass -- with (1, 0) as its affine
-    // part, since the weights hold gamma and beta either way -- fused with the split-K fix-up as before.
-    static const bool no_ln_fold = dev_switch("AMX_NO_LN_FOLD");  // developer A/B switch
-    void *ln_rowps = nullptr, *ln_coef = nullptr, *ln_partial = nullptr;
-    bool fold = false;
-    auto as_consumer = [&](GemmParams g, const float* col_c) {
-        g.row_coef = (const float2*)ln_coef; g.col_c = col_c;
-        return g;
-    };
-    // Two-plane modes: between the products of a layer the stream lives in its planes only -- a producer reads its residual from
-    // them and writes fp32 rows only where something reads those (`f32`: a published hidden state, the last layer: the final
-    // LayerNorm and the unpacking read fp32).  AMX_FOLD_F32_STREAM=1: developer A/B switch (fp32 rows in and out of every producer).
+    // ---- the plan as a value ----
+    P.h = h;
+    P.flags = flags;
+    P.N = N;
+    P.L = L;
+    P.d_audio = d_audio;
+    P.d_out = d_out;
+    P.total = total;
+    P.NT = NT;
+    P.prec = prec;
+    P.C = C;
+    P.D = D;
+    P.F = F;
+    P.H = H;
+    P.T = T;
+    P.Tp = Tp;
+    P.TpTot = TpTot;
+    P.Tpad = Tpad;
+    P.cg = cg;
+    P.dh = dh;
+    P.dhp = dhp;
+    P.E = E;
+    P.Eld = Eld;
+    P.M = M;
+    P.Mp = Mp;
+    P.Mrows = Mrows;
+    P.Mh = Mh;
+    P.rows1 = rows1;
+    P.rows2 = rows2;
+    P.xp_plane = xp_plane;
+    P.qk_plane = qk_plane;
+    P.qkv_bytes = qkv_bytes;
+    P.keep = keep;
+    P.masked = masked;
+    P.stable = stable;
+    P.packed = packed;
+    P.packed_early = packed_early;
+    P.ragged = ragged;
+    P.window_ok = window_ok;
+    P.needs_qkv_zero = needs_qkv_zero;
+    P.blanks = blanks;
+    P.d_len = d_len;
+    P.d_frames = d_frames;
+    P.d_rowoff = d_rowoff;
+    P.d_partial = d_partial;
+    P.d_stats = d_stats;
+    P.actA = actA;
+    P.actB = actB;
+    P.preln = preln;
+    P.hbuf = hbuf;
+    P.xp = xp;
+    P.hg = hg;
+    P.qb = qb;
+    P.kb = kb;
+    P.vtb = vtb;
+    P.ao = ao;
+    P.ff = ff;
+    P.hfin = hfin;
+    P.logits = logits;
+    P.hpk = hpk;
+    P.splitk = splitk;
+    P.gn_partial = gn_partial;
+    P.gn_scale = gn_scale;
+    P.gn_shift = gn_shift;
+    P.ebuf = ebuf;
+    P.cat = cat;
+    P.tl_x = tl_x;
+    P.tl_p = tl_p;
+    P.tl_qkv = tl_qkv;
+    P.d_frames_enc = d_frames_enc;
+    P.d_tiles = d_tiles;
+    P.conv_dbg = conv_dbg;
+    P.hfin_rows = hfin_rows;
+    P.stream = stream;
+    for (int i = 0; i <= AMX_MAX_CONV; ++i) { P.Ts[i] = i <= c.n_conv ? Ts[i] : 0; P.tile_first[i] = tile_first[i]; }
+    P.saved = saved;
+    if (packed_early) {
+        P.rowoff_host.assign(pin_rowoff, pin_rowoff + N);
+        P.frames_host.assign(pin_frames, pin_frames + N);
+    }
+    // LayerNorm fold: decided on the products as they will be launched (AMX_NO_LN_FOLD / AMX_FOLD_F32_STREAM: developer A/B switches)
+    static const bool no_ln_fold = dev_switch("AMX_NO_LN_FOLD");
     static const bool f32_stream = dev_switch("AMX_FOLD_F32_STREAM");
-    const bool stream_in_planes = NT == 2 && !f32_stream;
-    auto as_producer = [&](GemmParams g, bool f32 = true) {
-        g.ln_partial = (float2*)ln_partial; g.ln_rowps = (const float4*)ln_rowps;
-        g.out_p = xp; g.out_plane = xp_plane; g.ldp = D;
-        if (stream_in_planes) {
-            g.ln_res_planes = 1;
-            g.residual = nullptr;
-            if (!f32) g.out_f32 = nullptr;
-        }
-        return g;
-    };
+    P.stream_in_planes = NT == 2 && !f32_stream;
     if (stable && !no_ln_fold && c.layers > 0 && D % 64 == 0 && D <= 1024) {
-        WS("ln_rowps", (size_t)Mrows * 16, ln_rowps);
-        WS("ln_coef", (size_t)Mrows * 8, ln_coef);
-        WS("ln_partial", (size_t)Mrows * (D / 64) * 8, ln_partial);
+        WS("ln_rowps", (size_t)Mrows * 16, P.ln_rowps);
+        WS("ln_coef", (size_t)Mrows * 8, P.ln_coef);
+        WS("ln_partial", (size_t)Mrows * (D / 64) * 8, P.ln_partial);
         const Layer& ly = h->layers[0];
-        fold = gemm_ln_fold_ok(prec, as_consumer(qkv_params(ly), ly.c_qkv)) && gemm_ln_fold_ok(prec, as_producer(oproj_params(ly))) &&
-               gemm_ln_fold_ok(prec, as_consumer(ffn1_params(ly), ly.c_1)) && gemm_ln_fold_ok(prec, as_producer(ffn2_params(ly)));
+        P.fold = gemm_ln_fold_ok(prec, P.as_consumer(P.qkv_params(ly), ly.c_qkv)) && gemm_ln_fold_ok(prec, P.as_producer(P.oproj_params(ly))) &&
+                 gemm_ln_fold_ok(prec, P.as_consumer(P.ffn1_params(ly), ly.c_1)) && gemm_ln_fold_ok(prec, P.as_producer(P.ffn2_params(ly)));
     }
     ++h->pass_counter;
-    h->last_fold = fold;
+    h->last_fold = P.fold;
     h->last_packed = packed_early ? 2 : (packed ? 1 : 0);
     h->last_rows = Mrows;
     h->last_graph = 0;
-    void* const hbuf_plan = hbuf;
+#undef WS
+    return AMX_OK;
+}
 
-    // =============================================================================================================
-    // enqueue: the whole pass on stream `s` -- memsets, kernels, device-to-device copies only (eagerly on the caller's
-    // stream, or once on the capture stream when the pass is recorded into a HIP graph)
-    // =============================================================================================================
-    auto enqueue = [&](hipStream_t s) -> int {
-    void* hbuf = hbuf_plan;  // (local: the region may run twice -- once into a recording that fails, then eagerly)
+// The enqueue region: the whole pass on stream `s` -- kernels only (zero fills and device copies are kernels too: amx_rowops.hip,
+// launch_zero), nothing that allocates, uploads or synchronises.
+static int enqueue_pass(amx_handle h, const PassPlan& P, hipStream_t s) {
+    const amx_config& c = h->cfg;
+    const auto flags = P.flags;
+    const auto N = P.N;
+    const auto L = P.L;
+    const auto d_audio = P.d_audio;
+    const auto d_out = P.d_out;
+    const auto total = P.total;
+    const auto NT = P.NT;
+    const auto prec = P.prec;
+    const auto C = P.C;
+    const auto D = P.D;
+    const auto F = P.F;
+    const auto H = P.H;
+    const auto T = P.T;
+    const auto Tp = P.Tp;
+    const auto TpTot = P.TpTot;
+    const auto Tpad = P.Tpad;
+    const auto cg = P.cg;
+    const auto dh = P.dh;
+    const auto dhp = P.dhp;
+    const auto E = P.E;
+    const auto Eld = P.Eld;
+    const auto M = P.M;
+    const auto Mp = P.Mp;
+    const auto Mrows = P.Mrows;
+    const auto Mh = P.Mh;
+    const auto rows1 = P.rows1;
+    const auto rows2 = P.rows2;
+    const auto xp_plane = P.xp_plane;
+    const auto qk_plane = P.qk_plane;
+    const auto qkv_bytes = P.qkv_bytes;
+    const auto keep = P.keep;
+    const auto masked = P.masked;
+    const auto stable = P.stable;
+    const auto packed = P.packed;
+    const auto packed_early = P.packed_early;
+    const auto ragged = P.ragged;
+    const auto window_ok = P.window_ok;
+    const auto needs_qkv_zero = P.needs_qkv_zero;
+    const auto blanks = P.blanks;
+    const auto d_len = P.d_len;
+    const auto d_frames = P.d_frames;
+    const auto d_rowoff = P.d_rowoff;
+    const auto d_partial = P.d_partial;
+    const auto d_stats = P.d_stats;
+    const auto actA = P.actA;
+    const auto actB = P.actB;
+    const auto preln = P.preln;
+    void* hbuf = P.hbuf;  // (local: the layers switch it to the packed stream and back)
+    const auto xp = P.xp;
+    const auto hg = P.hg;
+    const auto qb = P.qb;
+    const auto kb = P.kb;
+    const auto vtb = P.vtb;
+    const auto ao = P.ao;
+    const auto ff = P.ff;
+    const auto hfin = P.hfin;
+    const auto logits = P.logits;
+    const auto hpk = P.hpk;
+    const auto splitk = P.splitk;
+    const auto gn_partial = P.gn_partial;
+    const auto gn_scale = P.gn_scale;
+    const auto gn_shift = P.gn_shift;
+    const auto ebuf = P.ebuf;
+    const auto cat = P.cat;
+    const auto tl_x = P.tl_x;
+    const auto tl_p = P.tl_p;
+    const auto tl_qkv = P.tl_qkv;
+    const auto d_frames_enc = P.d_frames_enc;
+    const auto d_tiles = P.d_tiles;
+    const auto conv_dbg = P.conv_dbg;
+    const auto hfin_rows = P.hfin_rows;
+    const auto stream = P.stream;
+    const auto& Ts = P.Ts;
+    const auto& tile_first = P.tile_first;
+    const auto& saved = P.saved;
+    const bool fold = P.fold, stream_in_planes = P.stream_in_planes;
+    void* const ln_rowps = P.ln_rowps; void* const ln_coef = P.ln_coef; void* const ln_partial = P.ln_partial;
+    (void)F; (void)rows2; (void)total; (void)Mh; (void)E; (void)hfin; (void)stream; (void)blanks; (void)ln_coef; (void)stream_in_planes;
+    (void)ff; (void)splitk; (void)hfin_rows; (void)qk_plane; (void)dh; (void)Tp; (void)cg; (void)Eld;
+    auto run_gemm = [&](int precision, GemmParams& g, hipStream_t stream_) { g = P.with_ws(g); launch_gemm(precision, g, stream_); };
     // K/V/Q padding rows [T, Tp) must stay finite: re-zero when the geometry changes
     // (zero fills inside a pass are kernels, never memsets: amx_rowops.hip, launch_zero)
     if (needs_qkv_zero) {
@@ -1867,8 +2065,8 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             }
         }
         {
-            GemmParams g = qkv_params(ly);
-            if (fold) g = as_consumer(g, ly.c_qkv);
+            GemmParams g = P.qkv_params(ly);
+            if (fold) g = P.as_consumer(g, ly.c_qkv);
             { Timed t_(h, gemm_class(prec, g)); launch_gemm(prec, g, s); }
         }
         {
@@ -1883,28 +2081,28 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             { Timed t_(h, AMX_KC_ATTENTION); launch_attention(prec, a, s); }
         }
         if (fold) {
-            residual_gemm(as_producer(oproj_params(ly), false), false);  // (nothing reads the stream between the two halves of a layer)
+            residual_gemm(P.as_producer(P.oproj_params(ly), false), false);  // (nothing reads the stream between the two halves of a layer)
             ln_finalize();
         } else {
-            residual_gemm(oproj_params(ly), true);
+            residual_gemm(P.oproj_params(ly), true);
             // pre-LN: the LayerNorm in front of the FFN (`final_layer_norm`); post-LN: `layer_norm` behind the attention residual
             if (stable) stream_norm(h->unit_g, h->zero_b, Mrows, xp_plane, nullptr);
             else stream_norm(ly.ln1_g, ly.ln1_b, Mrows, xp_plane, ln_inplace);
         }
         {
-            GemmParams g = ffn1_params(ly);
-            if (fold) g = as_consumer(g, ly.c_1);
+            GemmParams g = P.ffn1_params(ly);
+            if (fold) g = P.as_consumer(g, ly.c_1);
             { Timed t_(h, gemm_class(prec, g)); launch_gemm(prec, g, s); }
         }
         if (fold && (l + 1 < c.layers || stream_in_planes)) {
             // fp32 rows where the next reader needs them: hidden state l + 1 is published, or this is the last layer (final LayerNorm,
             // unpacking); the last layer's planes and statistics have no reader (it is a producer for the residual's sake)
             const bool last = l + 1 == c.layers;
-            residual_gemm(as_producer(ffn2_params(ly), last || saved[l + 1] != nullptr), false);
+            residual_gemm(P.as_producer(P.ffn2_params(ly), last || saved[l + 1] != nullptr), false);
             if (!last) ln_finalize();
         } else {
             // (the last layer of a packed batch is followed by the unpacking, not by a LayerNorm of these rows)
-            residual_gemm(ffn2_params(ly), !fold && !(packed && !packed_early && l == c.layers - 1));
+            residual_gemm(P.ffn2_params(ly), !fold && !(packed && !packed_early && l == c.layers - 1));
         }
         if (!stable) stream_norm(ly.ln2_g, ly.ln2_b, Mrows, xp_plane, ln_inplace);  // `final_layer_norm` closes the post-LN layer
     }
@@ -1978,7 +2176,30 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
                           packed_early ? (const int*)d_rowoff : nullptr, s); }
     HIPCHK(h, hipGetLastError());
     return AMX_OK;
-    };  // enqueue
+}
+
+extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* lengths, int N, int64_t L, float* out,
+                           int64_t* out_lengths, uint32_t flags, void* stream_) {
+    if (!h) return AMX_EINVAL;
+    if (!audio || !lengths || !out) return fail(h, AMX_EINVAL, "null buffer");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream_;
+    int rc;
+    // Safe by default: the reference computes in fp32 and cannot overflow (estimator.py:1035-1046); the fp16 planes can.  A
+    // pass that produced non-finite logits on valid frames is reported -- AMX_ERANGE -- by the first amx_forward /
+    // amx_synchronize issued after it has completed; nothing of THIS call has been enqueued when that happens.  No host
+    // synchronisation: only passes whose trailing event has completed are read.
+    if (!(flags & AMX_FLAG_NO_RANGE_CHECK) && (rc = range_poll(h, false))) return rc;
+    rc = compute_layout(h, N, L);
+    if (rc) return rc;
+    PassPlan P;
+    if ((rc = plan_pass(h, audio, lengths, N, L, out, out_lengths, flags, s, P))) return rc;
+    const float* const d_audio = P.d_audio;
+    float* const d_out = P.d_out;
+    const bool needs_qkv_zero = P.needs_qkv_zero, packed = P.packed, ragged = P.ragged, packed_early = P.packed_early, keep = P.keep;
+    const int64_t total = P.total;
+    const int T = P.T;
+    auto enqueue = [&](hipStream_t stream) -> int { return enqueue_pass(h, P, stream); };
 
     // ---- run the pass: replay its graph, record one, or enqueue it eagerly ----
     const bool graph_ok = !h->graph_broken && !(flags & (AMX_FLAG_NO_GRAPH | AMX_FLAG_TIMING | AMX_FLAG_KEEP_HIDDEN));
@@ -2077,11 +2298,10 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
     h->last_N = N; h->last_L = L; h->last_T = T; h->last_keep = keep;
     h->last_packed_rows = packed_early;
     if (packed_early) {
-        h->last_rowoff.assign(pin_rowoff, pin_rowoff + N);
-        h->last_frames.assign(pin_frames, pin_frames + N);
+        h->last_rowoff = P.rowoff_host;
+        h->last_frames = P.frames_host;
     }
     h->qkv_dirty = packed;  // a packed call leaves other rows in the Q / K / V planes: the next padded call re-zeroes them
-#undef WS
     // a host-I/O call has synchronised and handed the outputs over already: its own range report does not wait for the next call
     if (report_now && (rc = range_poll(h, true))) return rc;
     return AMX_OK;
