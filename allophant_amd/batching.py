@@ -210,11 +210,21 @@ class Prefetcher:
     objects, or anything ``fetch`` turns into one (e.g. index lists).  Batches that come out of a ``PinnedCollator`` carry
     their slot with them; the collator is told the event behind which the copy out of that slot has completed."""
 
-    def __init__(self, batches: Iterable, device: torch.device, fetch=None):
+    def __init__(self, batches: Iterable, device: torch.device, fetch=None, ring: int = 0):
+        """``ring`` > 0: device audio buffers are REUSED -- ``ring`` of them per batch shape, handed out in turn -- instead of coming
+        fresh from the caching allocator: a recording of a forward pass holds the addresses of its buffers (``amx_forward``), so a
+        loop that wants its passes replayed has to present the same ones again.  The copy into a slot waits (on the copy stream)
+        for everything the compute stream had been given when the slot's previous batch had been consumed, i.e. one ``next()``
+        later -- the loop ``for batch in prefetcher: predict(batch)`` is the contract (``ring`` >= 2)."""
         self._source = iter(batches)
         self._device = torch.device(device)
         self._fetch = fetch
         self._stream = torch.cuda.Stream(self._device)
+        self._ring = int(ring)
+        self._slots = {}       # shape -> [device tensors]
+        self._turn = {}        # shape -> next slot
+        self._history = []     # (shape, slot) of the batches handed out, newest last
+        self._events = {}      # (shape, slot) -> event on the compute stream behind the forward pass that read the slot
 
     @property
     def copy_stream(self) -> "torch.cuda.Stream":
@@ -227,8 +237,33 @@ class Prefetcher:
         item = next(self._source)
         batch = self._fetch(item) if self._fetch is not None else item
         audio = batch.audio_features if batch.audio_features.is_pinned() else batch.audio_features.pin_memory()
+        ring_key = None
+        if self._ring > 0:
+            current = torch.cuda.current_stream(self._device)
+            if self._history:
+                # everything enqueued so far includes the forward pass of the batch handed out last: its slot is free behind this
+                event = torch.cuda.Event()
+                event.record(current)
+                self._events[self._history[-1]] = event
+            shape = tuple(audio.shape)
+            slots = self._slots.setdefault(shape, [])
+            turn = self._turn.get(shape, 0)
+            if len(slots) < self._ring:
+                slots.append(torch.empty(shape, dtype=audio.dtype, device=self._device))
+                turn = len(slots) - 1
+            self._turn[shape] = (turn + 1) % self._ring
+            ring_key = (shape, turn)
+            if ring_key in self._events:
+                self._stream.wait_event(self._events.pop(ring_key))
+            elif ring_key in self._history[-1:]:
+                self._stream.wait_stream(current)  # (ring of one: the batch just handed out still owns the slot)
         with torch.cuda.stream(self._stream):
-            dev = audio.to(self._device, non_blocking=True)
+            if ring_key is not None:
+                dev = self._slots[ring_key[0]][ring_key[1]]
+                dev.copy_(audio, non_blocking=True)
+                self._history = (self._history + [ring_key])[-2:]
+            else:
+                dev = audio.to(self._device, non_blocking=True)
             slot = getattr(batch, "_pinned_slot", None)
             if slot is not None:
                 event = torch.cuda.Event()
@@ -236,7 +271,8 @@ class Prefetcher:
                 slot[0].mark_in_flight(batch, event)
         current = torch.cuda.current_stream(self._device)
         current.wait_stream(self._stream)  # stream-ordered: later launches on the compute stream see the copied batch
-        dev.record_stream(current)
+        if ring_key is None:
+            dev.record_stream(current)
         moved = Batch(dev, batch.lengths, batch.language_ids)
         if getattr(batch, "_padded", False):
             moved._padded = True
