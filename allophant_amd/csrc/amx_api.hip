@@ -170,6 +170,7 @@ struct amx_handle_s {
         hipGraphExec_t exec = nullptr;
         hipGraph_t graph = nullptr;  // the template stays alive as long as its instance (destroyed together)
         uint64_t last_use = 0;
+        hipStream_t last_stream = nullptr;  // where it was launched last: waited for before the instance is destroyed
     };
     static constexpr int GRAPH_CAP = 32;  // (a length-sorted corpus on a grid of batch geometries cycles through two dozen of them)
     std::vector<GraphEntry> graphs;
@@ -2209,6 +2210,9 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         key.reserve(10 + (size_t)N);
         key.insert(key.end(), {(int64_t)(intptr_t)d_audio, (int64_t)(intptr_t)d_out, (int64_t)N, L, (int64_t)flags, (int64_t)needs_qkv_zero,
                                (int64_t)h->inv, (int64_t)h->inventories[h->inv].generation, (int64_t)h->ws_gen});
+        // (the stream is part of the key: an executable graph is launched on one stream at a time -- a handle is meant for one
+        // stream, include/allophant_amx.h, but a caller that moves to another one gets a recording of its own, not a shared one)
+        key.push_back((int64_t)(intptr_t)s);
         // A recording is keyed on GEOMETRY where it can be (ABI 6): in the padded layout without tile skipping every kernel reads
         // lengths / frame counts / masks from the device buffers the plan region has just refreshed (no length travels by value in a
         // kernel node), so batches of one (N, L) with different lengths -- the reference's loop feeds a new batch every iteration,
@@ -2216,7 +2220,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
         // those passes keep them in the key.
         key.push_back(packed ? 2 : (ragged ? 1 : 0));
         if (packed || ragged) key.insert(key.end(), lengths, lengths + N);
-        if (!h->graphs.empty() && h->graphs.front().key.size() >= 10 && h->graphs.front().key[8] != (int64_t)h->ws_gen) {
+        if (!h->graphs.empty() && h->graphs.front().key.size() >= 11 && h->graphs.front().key[8] != (int64_t)h->ws_gen) {
             // a workspace buffer moved since these were recorded (ws_get synchronised the device before freeing it)
             drop_graphs(h);
         }
@@ -2224,6 +2228,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
             if (g.key == key) {
                 HIPCHK(h, hipGraphLaunch(g.exec, s));
                 g.last_use = ++h->graph_clock;
+                g.last_stream = s;
                 ++h->graph_replays;
                 h->last_graph = 2;
                 done = true;
@@ -2249,7 +2254,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
                         size_t lru = 0;
                         for (size_t i = 1; i < h->graphs.size(); ++i)
                             if (h->graphs[i].last_use < h->graphs[lru].last_use) lru = i;
-                        HIPCHK(h, hipStreamSynchronize(s));
+                        HIPCHK(h, hipStreamSynchronize(h->graphs[lru].last_stream));  // (its last launch may be on another stream than `s`)
                         (void)hipGraphExecDestroy(h->graphs[lru].exec);
                         if (h->graphs[lru].graph) (void)hipGraphDestroy(h->graphs[lru].graph);
                         h->graphs.erase(h->graphs.begin() + (long)lru);
@@ -2267,6 +2272,7 @@ extern "C" int amx_forward(amx_handle h, const float* audio, const int64_t* leng
                         entry.graph = nullptr;
                     }
                     entry.last_use = ++h->graph_clock;
+                    entry.last_stream = s;
                     h->graphs.push_back(std::move(entry));
                     ++h->graph_captures;
                     h->last_graph = 1;

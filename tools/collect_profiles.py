@@ -10,6 +10,7 @@ Infinity Cache are counted.  FETCH_SIZE and WRITE_SIZE come from separate --pmc 
 """
 import json
 import os
+import re
 import shutil
 import sys
 
@@ -49,7 +50,8 @@ for arg in sys.argv[2:]:
         for kernel, row in sorted(mfma.items(), key=lambda kv: -kv[1]["mfma_busy_frac"])[:4]:
             print(f"  mfma busy {row['mfma_busy_frac']:.3f}  {kernel[-70:]}")
     # the dominant kernel: the 256-row instance of the ping-pong GEMM (the 128-row instance is the last conv layer)
-    gemm = [v for k, v in merged.items() if "gemm_pp_kernel" in k and ("Li8EE" in k or ",8>" in k.replace(" ", ""))] or \
+    # (round 6: the instances carry the tile width and the LayerNorm-fold role behind the tile height: <T, planes, 8, NI, FOLD>)
+    gemm = [v for k, v in merged.items() if re.search(r"gemm_pp_kernelI\w+?Li[12]ELi8E", k) or ",8>" in k.replace(" ", "") or ", 8, " in k] or \
            [v for k, v in merged.items() if "gemm_pp_kernel" in k]
     if not gemm:
         raise SystemExit(f"no gemm_pp_kernel counters in {src}")
