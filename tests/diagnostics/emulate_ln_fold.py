@@ -12,7 +12,9 @@ Linear-shaped product of a layer as hi.hi + lo.hi + hi.lo on f16 planes with fp3
             c = W gamma, d = W beta + b (fp64 at create)
   fold_nopivot   the same with p = 0 and s = 1 (what a pivot-free form would do; DC offsets then cancel in fp32 after the product)
   fold_planes    fold, with the residual stream kept ONLY as those planes between the products (no fp32 copy: the next residual is
-                 (hi + lo) / s + p) -- not built; priced here
+                 (hi + lo) / s + p): what the two-plane modes run
+  fold_planes_fixed   the same with the pivot and the scale of a row FIXED for the whole stack at what the first norm gave (one pair
+                 of row parameters per pass instead of one per product)
 
 Weight families: those of tests/test_gpu_range.py (plain, scales, student_t, ln_gain, outlier) plus `dc30`: every row of the
 residual stream carries a DC offset of ~ 30 sigma.
@@ -86,8 +88,9 @@ def encoder_layers(h, bias, state, spec, scheme):
     dh = D // H
     hidden = []
     fold = scheme.startswith("fold")
-    pivot = scheme in ("fold", "fold_planes")
-    planes_only = scheme == "fold_planes"
+    pivot = scheme in ("fold", "fold_planes", "fold_planes_fixed")
+    planes_only = scheme in ("fold_planes", "fold_planes_fixed")
+    fixed = scheme == "fold_planes_fixed"  # pivot and scale of a row stay what the first norm of the stack gave
     x = h.reshape(N * T, D).clone()
     M = x.shape[0]
     if fold:
@@ -132,7 +135,7 @@ def encoder_layers(h, bias, state, spec, scheme):
                 # the stream exists as planes only: the next residual is what they hold, under the pivot / scale they were written with
                 uh, ul = split(u)
                 x = (uh + ul) / s[:, None] + p[:, None]
-            if pivot:
+            if pivot and not fixed:
                 # what the NEXT producer writes its planes under
                 p = p + m1
                 s = pow2_floor(16.0 * rstd)
@@ -205,7 +208,7 @@ def main():
         row = hid[2].reshape(-1, hid[2].shape[-1])
         ratio = (row.mean(-1).abs() / row.std(-1)).median().item()
         line = f"{fam:10s} |mean|/sigma of stream rows (layer 2) = {ratio:6.2f}  "
-        for scheme in ("current", "fold", "fold_nopivot", "fold_planes"):
+        for scheme in ("current", "fold", "fold_planes", "fold_planes_fixed"):
             got, _, _ = run(audio, lengths, state, spec, tfi, offsets, scheme)
             worst = 0.0
             for k_ in exact:
