@@ -37,6 +37,8 @@ def _large_groupnorm_encoder() -> Dict[str, Any]:
 # or the live-model binding `spec.spec_from_reference_model`, which reads the real config objects].
 MODEL_ID_ENCODERS = {
     "facebook/wav2vec2-xls-r-300m": _spec.xlsr_300m_encoder,           # every released Allophant checkpoint
+    "facebook/wav2vec2-xls-r-1b": _spec.xlsr_1b_encoder,               # hidden 1280 / head_dim 80 (round 6)
+    "facebook/wav2vec2-xls-r-2b": _spec.xlsr_2b_encoder,               # hidden 1920 / head_dim 120
     "facebook/wav2vec2-large-xlsr-53": _spec.xlsr_300m_encoder,        # same shape and variant (layer norm, pre-LN, mask)
     "facebook/wav2vec2-large-lv60": _spec.xlsr_300m_encoder,
     "facebook/wav2vec2-base": _spec.wav2vec2_base_encoder,             # group norm, post-LN, return_attention_mask=False

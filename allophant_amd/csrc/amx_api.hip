@@ -440,8 +440,8 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
     if (cfg->n_conv < 2 || cfg->n_conv > AMX_MAX_CONV) return fail(nullptr, AMX_EINVAL, "n_conv out of range");
     if (cfg->heads < 1 || cfg->hidden % cfg->heads != 0 || (cfg->hidden / cfg->heads) % 8 || cfg->hidden / cfg->heads > 128)
         return fail(nullptr, AMX_EINVAL, "head_dim (hidden / heads) must be a multiple of 8 and at most 128");
-    if (cfg->hidden > 1024 || cfg->hidden % 8 || cfg->conv_dim > 1024 || cfg->conv_dim % 8)
-        return fail(nullptr, AMX_EINVAL, "hidden and conv_dim must be multiples of 8 and <= 1024");
+    if (cfg->hidden > 2048 || cfg->hidden % 8 || cfg->conv_dim > 1024 || cfg->conv_dim % 8)
+        return fail(nullptr, AMX_EINVAL, "hidden must be a multiple of 8 and <= 2048, conv_dim a multiple of 8 and <= 1024");
     if (cfg->conv_dim >= 64 && cfg->conv_dim % 64) return fail(nullptr, AMX_EINVAL, "conv_dim must be < 64 or a multiple of 64");
     if (cfg->conv_kernel[0] > 16) return fail(nullptr, AMX_EINVAL, "first conv kernel must be <= 16");
     for (int i = 0; i < cfg->n_conv; ++i)
@@ -449,8 +449,8 @@ extern "C" int amx_create(amx_handle* out, int device, const amx_config* cfg, co
     if (conv0_window_lds_bytes(cfg->conv_kernel[0], cfg->conv_stride[0], cfg->feat_extract_norm == AMX_NORM_GROUP) > 64 * 1024)
         return fail(nullptr, AMX_EINVAL, "first conv stride too large for the LDS window of the conv-0 kernels (stride <= 16 with the "
                                          "group-norm extractor, <= 127 otherwise)");
-    if (cfg->hidden % cfg->pos_groups != 0 || (cfg->hidden / cfg->pos_groups) % 8 || cfg->hidden / cfg->pos_groups > 64)
-        return fail(nullptr, AMX_EINVAL, "hidden / pos_groups must be a multiple of 8 and <= 64");
+    if (cfg->hidden % cfg->pos_groups != 0 || (cfg->hidden / cfg->pos_groups) % 8 || cfg->hidden / cfg->pos_groups > 128)
+        return fail(nullptr, AMX_EINVAL, "hidden / pos_groups must be a multiple of 8 and <= 128");
     if (cfg->ffn % 8) return fail(nullptr, AMX_EINVAL, "ffn must be a multiple of 8");
     if (cfg->precision < 0 || cfg->precision > 3) return fail(nullptr, AMX_EINVAL, "unknown precision");
     if (cfg->feat_extract_norm != AMX_NORM_LAYER && cfg->feat_extract_norm != AMX_NORM_GROUP)
@@ -1747,7 +1747,7 @@ static int plan_pass(amx_handle h, const float* audio, const int64_t* lengths, i
     static const bool no_ln_fold = dev_switch("AMX_NO_LN_FOLD");
     static const bool f32_stream = dev_switch("AMX_FOLD_F32_STREAM");
     P.stream_in_planes = NT == 2 && !f32_stream;
-    if (stable && !no_ln_fold && c.layers > 0 && D % 64 == 0 && D <= 1024) {
+    if (stable && !no_ln_fold && c.layers > 0 && D % 64 == 0 && D <= 2048) {
         WS("ln_rowps", (size_t)Mrows * 16, P.ln_rowps);
         WS("ln_coef", (size_t)Mrows * 8, P.ln_coef);
         WS("ln_partial", (size_t)Mrows * (D / 64) * 8, P.ln_partial);

@@ -452,7 +452,7 @@ bool gemm_ln_fold_ok(int prec, const GemmParams& p_in) {
     if (splits != 1) return false;
     if (p.ln_partial) {
         // producer: fp32 stream + residual, planes of the new rows, whole 64-column blocks, 256-column tiles
-        if (ni != 4 || p.N % 64 || p.N > 1024 || !p.out_p || !p.ln_rowps || p.act || p.mode || p.row_len || p.row_coef) return false;
+        if (ni != 4 || p.N % 64 || p.N > 2048 || !p.out_p || !p.ln_rowps || p.act || p.mode || p.row_len || p.row_coef) return false;
         // the stream: fp32 rows in and out, or (two planes) the planes themselves as the residual and fp32 out only on request
         if (p.ln_res_planes ? NT != 2 : (!p.out_f32 || !p.residual)) return false;
         if (NT == 2 && (p.out_plane != PLANE_IL || p.ldp % 32)) return false;

@@ -829,9 +829,10 @@ __global__ __launch_bounds__(512) void conv0_gn_cov_final_kernel(const double* _
 
 // ----------------------------------------------------------------------------------------------------------------
 // Row kernel: x[M, D] fp32 -> [LayerNorm(g1,b1) -> optional GELU] -> [LayerNorm(g2,b2)] -> planes / fp32.
-// One wave per row, D <= 1024, D % 4 == 0, row kept in registers (float4 x 4 per lane).
+// One wave per row, D <= 256 V, D % 4 == 0, row kept in registers (float4 x V per lane; V = 4 up to hidden 1024 -- XLS-R 300M and
+// every released checkpoint --, V = 8 up to 2048: the XLS-R 1B / 2B widths 1280 / 1920, round 6).
 // ----------------------------------------------------------------------------------------------------------------
-template <typename T, int NT>
+template <typename T, int NT, int V = 4>
 // (x and out_f32 carry no __restrict__: the post-LN encoder normalises the residual stream IN PLACE, out_f32 == x; a wave loads
 // its whole row into registers before it stores any of it, and rows belong to one wave each)
 __global__ __launch_bounds__(256) void rownorm_kernel(const float* x, int64_t ldx, int64_t M, int D,
@@ -850,21 +851,21 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* x, int64_t ld
         if (t >= frame_len[n]) return;
         row = (int64_t)row_off[n] + t;
     }
-    float4 v[4];
+    float4 v[V];
     const float invD = 1.0f / (float)D;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < V; ++i) {
         int c = (i * 64 + lane) * 4;
         v[i] = c < D ? *(const float4*)(src + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     auto norm = [&](const float* g, const float* b, float eps, bool act) {
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) s += v[i].x + v[i].y + v[i].z + v[i].w;  // out-of-range entries are zero
+        for (int i = 0; i < V; ++i) s += v[i].x + v[i].y + v[i].z + v[i].w;  // out-of-range entries are zero
         const float mu = wave_sum(s) * invD;
         float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < V; ++i) {
             int c = (i * 64 + lane) * 4;
             if (c < D) {
                 float dx = v[i].x - mu, dy = v[i].y - mu, dz = v[i].z - mu, dw = v[i].w - mu;
@@ -873,7 +874,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* x, int64_t ld
         }
         const float rs = 1.0f / sqrtf(wave_sum(q) * invD + eps);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < V; ++i) {
             int c = (i * 64 + lane) * 4;
             if (c < D) {
                 float4 gg = *(const float4*)(g + c), bb = *(const float4*)(b + c);
@@ -893,7 +894,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* x, int64_t ld
     if (g1) norm(g1, b1, eps1, gelu != 0);
     if (g2) norm(g2, b2, eps2, false);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < V; ++i) {
         int c = (i * 64 + lane) * 4;
         if (c < D) {
             if (out_f32) *(float4*)(out_f32 + row * ldo + c) = v[i];
@@ -928,7 +929,7 @@ __device__ __forceinline__ float ln_plane_scale(float rstd) {
 }
 
 // the first norm of the stack: exact statistics from the fp32 row (the arithmetic of rownorm_kernel), planes of (x - mu) * s
-template <typename T, int NT>
+template <typename T, int NT, int V = 4>
 __global__ __launch_bounds__(256) void ln_rowprep_kernel(const float* __restrict__ x, int64_t ldx, int64_t M, int D, float eps,
                                                          T* __restrict__ out_p, int64_t out_plane, int64_t ldp,
                                                          float4* __restrict__ rowps, float2* __restrict__ coef) {
@@ -936,20 +937,20 @@ __global__ __launch_bounds__(256) void ln_rowprep_kernel(const float* __restrict
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const float* src = x + row * ldx;
-    float4 v[4];
+    float4 v[V];
     const float invD = 1.0f / (float)D;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < V; ++i) {
         const int c = (i * 64 + lane) * 4;
         v[i] = c < D ? *(const float4*)(src + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) s += v[i].x + v[i].y + v[i].z + v[i].w;
+    for (int i = 0; i < V; ++i) s += v[i].x + v[i].y + v[i].z + v[i].w;
     const float mu = wave_sum(s) * invD;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < V; ++i) {
         const int c = (i * 64 + lane) * 4;
         if (c < D) {
             const float dx = v[i].x - mu, dy = v[i].y - mu, dz = v[i].z - mu, dw = v[i].w - mu;
@@ -963,7 +964,7 @@ __global__ __launch_bounds__(256) void ln_rowprep_kernel(const float* __restrict
         coef[row] = make_float2(rs / sc, 0.f);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < V; ++i) {
         const int c = (i * 64 + lane) * 4;
         if (c < D) {
             T hi[4], lo[4];
@@ -989,10 +990,10 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float2* __restri
     const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (row >= M) return;
     const float2* pr = partial + row * blocks;
-    float2 b[16];
+    float2 b[32];  // (hidden <= 2048)
     float s1 = 0.f;
 #pragma unroll
-    for (int j = 0; j < 16; ++j)
+    for (int j = 0; j < 32; ++j)
         if (j < blocks) {
             b[j] = pr[j];
             s1 += b[j].x;
@@ -1005,7 +1006,7 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float2* __restri
     const float mu = s1 * invD;  // mean of u
     float m2 = 0.f;
 #pragma unroll
-    for (int j = 0; j < 16; ++j)
+    for (int j = 0; j < 32; ++j)
         if (j < blocks) {
             const float d = b[j].x * (1.0f / 64.0f) - mu;
             m2 += fmaf(64.0f * d, d, b[j].y);
@@ -1656,18 +1657,24 @@ void launch_rownorm(int prec, const float* x, int64_t ldx, int64_t M, int D, con
                     int gelu, const float* gamma2, const float* beta2, float eps1, float eps2, void* out_p,
                     int64_t out_plane, int64_t ldp, float* out_f32, int64_t ldo, hipStream_t s) {
     dim3 grid((unsigned)((M + 3) / 4));
-    AMX_DISPATCH(prec, hipLaunchKernelGGL((rownorm_kernel<T16, NT>), grid, dim3(256), 0, s, x, ldx, M, D, gamma1, beta1, gelu,
-                                          gamma2, beta2, eps1, eps2, (T16*)out_p, out_plane, ldp, out_f32, ldo, nullptr, nullptr, 1));
+    if (D <= 1024) {
+        AMX_DISPATCH(prec, hipLaunchKernelGGL((rownorm_kernel<T16, NT, 4>), grid, dim3(256), 0, s, x, ldx, M, D, gamma1, beta1, gelu,
+                                              gamma2, beta2, eps1, eps2, (T16*)out_p, out_plane, ldp, out_f32, ldo, nullptr, nullptr, 1));
+    } else {
+        AMX_DISPATCH(prec, hipLaunchKernelGGL((rownorm_kernel<T16, NT, 8>), grid, dim3(256), 0, s, x, ldx, M, D, gamma1, beta1, gelu,
+                                              gamma2, beta2, eps1, eps2, (T16*)out_p, out_plane, ldp, out_f32, ldo, nullptr, nullptr, 1));
+    }
 }
 
 void launch_ln_rowprep(int prec, const float* x, int64_t ldx, int64_t M, int D, float eps, void* out_p, int64_t out_plane, int64_t ldp,
                        float4* rowps, float2* coef, hipStream_t s) {
     dim3 grid((unsigned)((M + 3) / 4));
-    switch (prec) {
-        case PREC_BF16: hipLaunchKernelGGL((ln_rowprep_kernel<bf16, 1>), grid, dim3(256), 0, s, x, ldx, M, D, eps, (bf16*)out_p, out_plane, ldp, rowps, coef); break;
-        case PREC_F16: hipLaunchKernelGGL((ln_rowprep_kernel<f16, 1>), grid, dim3(256), 0, s, x, ldx, M, D, eps, (f16*)out_p, out_plane, ldp, rowps, coef); break;
-        case PREC_BF16X3: hipLaunchKernelGGL((ln_rowprep_kernel<bf16, 2>), grid, dim3(256), 0, s, x, ldx, M, D, eps, (bf16*)out_p, out_plane, ldp, rowps, coef); break;
-        default: hipLaunchKernelGGL((ln_rowprep_kernel<f16, 2>), grid, dim3(256), 0, s, x, ldx, M, D, eps, (f16*)out_p, out_plane, ldp, rowps, coef); break;
+    if (D <= 1024) {
+        AMX_DISPATCH(prec, hipLaunchKernelGGL((ln_rowprep_kernel<T16, NT, 4>), grid, dim3(256), 0, s, x, ldx, M, D, eps, (T16*)out_p, out_plane,
+                                              ldp, rowps, coef));
+    } else {
+        AMX_DISPATCH(prec, hipLaunchKernelGGL((ln_rowprep_kernel<T16, NT, 8>), grid, dim3(256), 0, s, x, ldx, M, D, eps, (T16*)out_p, out_plane,
+                                              ldp, rowps, coef));
     }
 }
 

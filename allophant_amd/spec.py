@@ -75,6 +75,22 @@ def wav2vec2_base_encoder() -> Dict[str, Any]:
     }
 
 
+def xlsr_1b_encoder() -> Dict[str, Any]:
+    """``facebook/wav2vec2-xls-r-1b`` [memory: hidden 1280, 48 layers, 16 heads (head_dim 80), ffn 5120; the 300M model's feature
+    extractor and variant -- the hub is unreachable offline, ``checkpoint.check_encoder_against_state`` cross-checks the widths
+    and counts against the weights]."""
+    encoder = xlsr_300m_encoder()
+    encoder.update(hidden=1280, layers=48, heads=16, ffn=5120)
+    return encoder
+
+
+def xlsr_2b_encoder() -> Dict[str, Any]:
+    """``facebook/wav2vec2-xls-r-2b`` [memory: hidden 1920, 48 layers, 16 heads (head_dim 120), ffn 7680]."""
+    encoder = xlsr_300m_encoder()
+    encoder.update(hidden=1920, layers=48, heads=16, ffn=7680)
+    return encoder
+
+
 def tiny_encoder(layers: int = 2) -> Dict[str, Any]:
     """Reduced shape used by the committed golden vectors (same operator sequence as XLS-R)."""
     return {
@@ -304,6 +320,10 @@ def validate(spec: Dict[str, Any]) -> None:
         raise ValueError("hidden must be divisible by heads")
     if (spec["hidden"] // spec["heads"]) % 8 or spec["hidden"] // spec["heads"] > 128:
         raise ValueError("head_dim (hidden / heads) must be a multiple of 8 and at most 128 (amx_create)")
+    if spec["hidden"] > 2048 or spec["hidden"] % 8:
+        raise ValueError("hidden must be a multiple of 8 and at most 2048 (amx_create)")
+    if spec["hidden"] % spec["pos_groups"] or (spec["hidden"] // spec["pos_groups"]) % 8 or spec["hidden"] // spec["pos_groups"] > 128:
+        raise ValueError("hidden / pos_groups must be a multiple of 8 and at most 128 (amx_create)")
     if spec.get("feat_extract_norm", "layer") not in ("layer", "group"):
         # transformers' own message (Wav2Vec2FeatureEncoder.__init__)
         raise ValueError(f"`config.feat_extract_norm` is {spec['feat_extract_norm']}, but has to be one of ['group', 'layer']")

@@ -221,7 +221,7 @@ def integer_goldens():
 
 def main():
     torch.set_num_threads(8)
-    which = set(sys.argv[1:]) or {"g1", "g2", "g2b", "g3", "g4", "g5", "g8", "g11", "g11b", "g12", "g13", "g13b"}
+    which = set(sys.argv[1:]) or {"g1", "g2", "g2b", "g3", "g4", "g5", "g8", "g11", "g11b", "g12", "g13", "g13b", "g14"}
     tiny = S.tiny_encoder(2)
     if "g4" in which:
         integer_goldens()
@@ -320,6 +320,16 @@ def main():
         enc.update(hidden=64, heads=2, ffn=128, pos_groups=4, stable_layer_norm=False)
         spec = S.multitask_spec(enc, ["syllabic", "long", "nasal"], embedding_size=16, train_phonemes=9, n_features=5)
         run_case("g13b_tiny_head_dim_32", spec, n=2, length=5200, ragged=True, inventory_phones=6, seed=14, store_weights=False)
+    if "g14" in which:
+        # G14 (round 6): the WIDTH of the XLS-R 1B encoder -- hidden 1280, 16 heads of 80, positional convolution with 80 channels per
+        # group -- on two layers and a narrow ffn (rows wider than 1024: the row kernels' second instance, the fold's 20 blocks per
+        # row, the grouped positional convolution beyond 64 channels per group); 2 x 2 s ragged, sub-sampled tensors only
+        enc = S.tiny_encoder(2)
+        enc.update(hidden=1280, heads=16, ffn=2560, pos_groups=16, pos_kernel=128, conv_dim=64)
+        spec = S.multitask_spec(enc, ["syllabic", "long", "nasal"], embedding_size=32, train_phonemes=12, n_features=6, allophone_layer=True)
+        spec["shared_phones"] = 14
+        run_case("g14_xlsr1b_width", spec, n=2, length=32000, ragged=True, inventory_phones=9, seed=14, store_weights=False,
+                 subsample=[0, 1, 2], store_audio=False)
     if "g3" in which:
         # G3: full XLS-R shape, procedural weights (seed 0), 2 x 3 s ragged; sub-sampled tensors only
         spec = S.multitask_spec(S.xlsr_300m_encoder(), allophone_layer=True)

@@ -92,3 +92,51 @@ def test_heads_wider_than_128_are_refused(amd):
     handle = C.c_void_p()
     code = L.load().amx_create(C.byref(handle), 0, C.byref(cfg), descs, len(descs), (L.AmxTensor * 1)(), 0)
     assert code == L.AMX_EINVAL and b"head_dim" in L.load().amx_last_error(None)
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "bf16x3"])
+def test_xlsr_1b_width_golden(amd, precision):
+    """Golden g14 from the real reference: hidden 1280 (rows wider than 1024: the second instance of the row kernels), 16 heads of
+    80, the positional convolution with 80 channels per group (the grouped implicit GEMM: the window kernel is the 64-channel
+    form), composition head -- the WIDTH of ``facebook/wav2vec2-xls-r-1b`` on two layers."""
+    g = Golden("g14_xlsr1b_width")
+    est = amd.Estimator(g.spec, g.state_dict(), "cuda:0", precision)
+    batch = amd.Batch(g.audio.cuda(), g.lengths, torch.zeros(len(g.lengths), dtype=torch.long))
+    for no_pack in (True, False):
+        pred = est.predict(batch, g.tfi, True, _no_pack=no_pack)
+        assert list(pred.outputs.keys()) == g.output_names and torch.equal(pred.lengths.cpu(), g.frame_lengths)
+        worst = max(max_abs_valid_tm(pred.outputs[k].cpu(), g.logprobs(k), g.frame_lengths) for k in g.output_names)
+        assert worst < GATE, (no_pack, worst)
+    pred = est.predict(batch, g.tfi, True, _keep_hidden=True)
+    for i in g.hidden_indices():
+        assert max_abs_valid_bm(est.debug_fetch("hidden", i)[:, :, ::8], g.hidden(i), g.frame_lengths) < GATE, i
+    est.close()
+
+
+@pytest.mark.parametrize("hidden,heads,ffn", [(1280, 16, 5120), (1920, 16, 7680)])
+def test_xlsr_1b_2b_shapes_large_batch_against_oracle(amd, hidden, heads, ffn):
+    """The XLS-R 1B / 2B layer shapes (``spec.xlsr_1b_encoder`` / ``xlsr_2b_encoder``, three layers of them) on 24 x 10 s: the
+    products run on the ping-pong kernel and the layers take the LayerNorm fold with 20 / 30 column blocks per row
+    (``amx_pass_info``); utterances 0 and 13 against the CPU oracle on each of them alone."""
+    from oracle import allophant_oracle as O
+
+    enc = S.xlsr_1b_encoder() if hidden == 1280 else S.xlsr_2b_encoder()
+    assert (enc["hidden"], enc["heads"], enc["ffn"]) == (hidden, heads, ffn)
+    enc["layers"] = 3
+    spec = S.multitask_spec(enc, ["syllabic", "long", "nasal"], embedding_size=64, train_phonemes=20, n_features=8, allophone_layer=True)
+    spec["shared_phones"] = 24
+    state = synthetic.make_state_dict(spec, seed=hidden)
+    tfi = synthetic.make_inventory(spec, 15, seed=2)
+    audio, lengths = synthetic.make_audio(24, 160000, seed=hidden + 1)
+    est = amd.Estimator(spec, state, "cuda:0", "f16x3")
+    pred = est.predict(amd.Batch(audio.cuda(), lengths, torch.zeros(24, dtype=torch.long)), tfi, True)
+    info = est.pass_info()
+    assert info["ln_fold"] == 1, info
+    est.check_finite()
+    offsets = synthetic.category_offsets(spec)
+    for i in (0, 13):
+        ref, ref_len = O.predict(audio[i:i + 1].contiguous(), lengths[i:i + 1], state, spec, tfi, offsets)
+        t_i = int(ref_len[0])
+        worst = max((pred.outputs[k][:t_i, i].cpu() - ref[k][:t_i, 0]).abs().max().item() for k in ref)
+        assert worst < GATE, (i, worst)
+    est.close()

@@ -162,3 +162,17 @@ def test_c_oracle_greedy_ctc(oracle_c):
             assert np.array_equal(tokens[i, :k], z[f"ctc/{ci}/tokens/{i}"])
             assert np.array_equal(timesteps[i, :k], z[f"ctc/{ci}/timesteps/{i}"])
             assert abs(scores[i] - float(z[f"ctc/{ci}/score/{i}"])) < 1e-3
+
+
+def test_oracle_matches_reference_xlsr_1b_width():
+    """Golden g14 (round 6): hidden 1280 / 16 heads of 80 / 80 channels per positional-convolution group -- the width of XLS-R 1B --
+    on two layers; sub-sampled golden tensors."""
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    g = Golden("g14_xlsr1b_width")
+    assert g.spec["hidden"] == 1280 and g.spec["hidden"] // g.spec["heads"] == 80
+    out, flen, inter = O.predict(g.audio, g.lengths, g.state_dict(), g.spec, g.tfi, g.category_offsets, True, keep_intermediates=True)
+    assert list(out.keys()) == g.output_names and torch.equal(flen, g.frame_lengths)
+    worst = max(max_abs_valid_tm(out[k], g.logprobs(k), g.frame_lengths) for k in g.output_names)
+    assert worst < 5e-5, worst
+    for i in g.hidden_indices():
+        assert max_abs_valid_bm(inter["hidden_states"][i][:, :, ::8], g.hidden(i), g.frame_lengths) < 5e-5, i
