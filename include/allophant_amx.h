@@ -91,13 +91,13 @@ typedef struct amx_config {
     int32_t conv_dim;                    /* 512 */
     int32_t conv_kernel[AMX_MAX_CONV];   /* 10,3,3,3,3,2,2 */
     int32_t conv_stride[AMX_MAX_CONV];   /* 5,2,2,2,2,2,2 */
-    int32_t hidden;                      /* 1024 */
+    int32_t hidden;                      /* 1024 (a multiple of 8, at most 2048: XLS-R 1B / 2B have 1280 / 1920; ABI 6) */
     int32_t layers;                      /* 24 */
     int32_t heads;                       /* 16 (head_dim = hidden / heads: a multiple of 8, at most 128 -- 64 for every released
                                             checkpoint, 80 / 120 for XLS-R 1B / 2B shapes; ABI 6) */
     int32_t ffn;                         /* 4096 */
     int32_t pos_kernel;                  /* 128 */
-    int32_t pos_groups;                  /* 16 */
+    int32_t pos_groups;                  /* 16 (hidden / pos_groups: a multiple of 8, at most 128) */
     float eps;                           /* layer_norm_eps 1e-5 */
     int32_t do_normalize;                /* preprocessor do_normalize (acoustic_model.py:815,841-843) */
     int32_t dependency_blanks;           /* ProjectionConfig.dependency_blanks */
