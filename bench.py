@@ -421,13 +421,16 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
+        last = None
         if runner is not None:
-            runner.drain()  # the last gather completes (and is assembled on rank 0) inside the timed region
+            last = runner.drain()  # the last gather completes (and is assembled on rank 0) inside the timed region
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        if last is not None:
+            last.check_ranks()  # (outside the timed region: a rank that reported a range error with its shard fails the run here)
         t_tensor = torch.tensor([elapsed], dtype=torch.float64, device=device)
         if use_dist:
             dist.all_reduce(t_tensor, op=dist.ReduceOp.MAX)
