@@ -65,6 +65,8 @@ def build_encoder(name):
     `model_id` (acoustic_model.py:775-826): `w2v2-base` (768 / 12 / 12 / 3072), `w2v2-large` (1024 / 24 / 16 / 4096)."""
     if name == "w2v2-base":
         return S.wav2vec2_base_encoder()
+    if name in ("xlsr-1b", "xlsr-2b"):  # hidden 1280 / 1920, 48 layers, heads of 80 / 120 (round 6)
+        return S.xlsr_1b_encoder() if name == "xlsr-1b" else S.xlsr_2b_encoder()
     encoder = S.xlsr_300m_encoder()
     if name == "w2v2-large":
         encoder.update(feat_extract_norm="group", conv_bias=False, stable_layer_norm=False, use_attention_mask=False)
@@ -326,7 +328,7 @@ def main():
                     help="BASELINE.json config to time on one GPU: 2 (default, the configuration `metric` is quoted on; config 3 "
                          "under --gpus N), 4 (hierarchical, 64 x 5 s), 5 (8 x 60 s, 200 phones) or 1 (baseline schema, 1 x 3 s: the "
                          "reference's CPU-runnable case, here on the device)")
-    ap.add_argument("--encoder", default="xlsr", choices=["xlsr", "w2v2-base", "w2v2-large"],
+    ap.add_argument("--encoder", default="xlsr", choices=["xlsr", "w2v2-base", "w2v2-large", "xlsr-1b", "xlsr-2b"],
                     help="wav2vec 2.0 shape and variant: xlsr (default; `metric` is quoted on it) or the group-norm / post-LN family "
                          "(informational lines: other work per frame)")
     ap.add_argument("--utterances", type=int, default=None, help="utterances of the (global) batch (default: the config's)")
@@ -474,7 +476,7 @@ def main():
         stage_flops = w["conv0"] + w["gemm_ln"] + w["conv_tail"]
         roofline = {
             "kernel": "gemm_pp_kernel<T16, planes, 8>: persistent ping-pong GEMM on 256x256 tiles (128x256 when a product cannot "
-                      "fill the chip): feature projection, QKV / out-proj / FFN of the 24 encoder layers, phoneme head",
+                      f"fill the chip): feature projection, QKV / out-proj / FFN of the {spec['encoder']['layers']} encoder layers, phoneme head",
             "bound": "mfma",
             "achieved": achieved,
             "peak": MFMA_PEAK_TFLOPS,

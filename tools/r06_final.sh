@@ -15,6 +15,8 @@ cp profiles/r06_traffic.json $O/r06_traffic.json
 (timeout 600 python bench.py --config 5 --also f16 > $O/r06_bench_config5.json 2>> $O/r06_bench_stderr.log)
 (timeout 600 python bench.py --config 1 --also "" > $O/r06_bench_config1.json 2>> $O/r06_bench_stderr.log)
 (timeout 600 python bench.py --encoder w2v2-base --also "" > $O/r06_bench_w2v2base.json 2>> $O/r06_bench_stderr.log)
+(timeout 900 python bench.py --encoder xlsr-1b --also "" --cpu-sample 4 > $O/r06_bench_xlsr1b.json 2>> $O/r06_bench_stderr.log)
+(timeout 1200 python bench.py --encoder xlsr-2b --also "" --cpu-sample 4 > $O/r06_bench_xlsr2b.json 2>> $O/r06_bench_stderr.log)
 G="1:3 4:10 8:10 16:10 32:10 1:60 8:60"
 rm -f $O/r06_geometry_sweep_final.log
 (timeout 600 python tools/geometry_sweep.py f16x3 $G 2>&1 | grep -v amdgpu.ids | sed 's/^/this tree    : /') >> $O/r06_geometry_sweep_final.log
@@ -39,11 +41,13 @@ done
 cd $ROOT
 python - <<'PY'
 import json
-for name in ("r06_bench_line", "r06_bench_config4", "r06_bench_config5", "r06_bench_config1", "r06_bench_w2v2base"):
+def r(x, n):
+    return None if x is None else round(x, n)
+for name in ("r06_bench_line", "r06_bench_config4", "r06_bench_config5", "r06_bench_config1", "r06_bench_w2v2base", "r06_bench_xlsr1b", "r06_bench_xlsr2b"):
     try:
         d = json.load(open(f"gpurun_out/{name}.json"))
-        print(name, round(d["ms_per_step"], 3), "ms", round(d["value"]), "frames/s ok", d.get("ok"), "frac", round(d["roofline"]["frac"], 4),
-              "whole_block", round(d["roofline"]["whole_block"]["frac"], 4), "conv0", round(d["roofline"]["conv_stage"]["conv0"]["frac"], 3),
+        print(name, round(d["ms_per_step"], 3), "ms", round(d["value"]), "frames/s ok", d.get("ok"), "frac", r(d["roofline"]["frac"], 4),
+              "whole_block", r(d["roofline"]["whole_block"]["frac"], 4), "conv0", r(d["roofline"]["conv_stage"]["conv0"]["frac"], 3),
               "spot", d.get("parity_spot_check", {}).get("max_abs"), "traffic", d["roofline"]["traffic"], "pass", d.get("pass"))
     except Exception as e:
         print(name, "ERROR", e)
