@@ -476,7 +476,7 @@ def main():
         stage_flops = w["conv0"] + w["gemm_ln"] + w["conv_tail"]
         roofline = {
             "kernel": "gemm_pp_kernel<T16, planes, 8>: persistent ping-pong GEMM on 256x256 tiles (128x256 when a product cannot "
-                      f"fill the chip): feature projection, QKV / out-proj / FFN of the {spec['encoder']['layers']} encoder layers, phoneme head",
+                      f"fill the chip): feature projection, QKV / out-proj / FFN of the {spec['layers']} encoder layers, phoneme head",
             "bound": "mfma",
             "achieved": achieved,
             "peak": MFMA_PEAK_TFLOPS,
