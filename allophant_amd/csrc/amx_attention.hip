@@ -83,9 +83,15 @@ __device__ __forceinline__ float sum_halves(float x) {
 // tile is then two [KT x 64] sub-tiles side by side in LDS, each in the layout of the dh = 64 kernel (same swizzles, same fragment
 // addresses), the score chain runs over both and O holds four 32-column blocks -- 64 more fragment and 32 more accumulator
 // registers, hence two waves per SIMD.  dh != 64 stores through the masked direct path (TSTORE's line patches assume 64 columns).
-template <typename T, int NT, int WAVES, int KT, bool PACKED, int KS = 1, bool TSTORE = true, int NDH = 1>
+// KQN: 16-column steps of the score chain that hold real columns (ceil(dh / 16); default: the whole padded row) and, with them, the
+// 32-column blocks of O that are kept ((KQN + 1) / 2).  The steps and blocks beyond are products with the zero padding -- leaving
+// them out changes no bit (x + 0 in the same order) and, at dh = 80 in a 128-wide row (XLS-R 1B), saves 3 of 8 score steps and 1 of
+// 4 output blocks.
+template <typename T, int NT, int WAVES, int KT, bool PACKED, int KS = 1, bool TSTORE = true, int NDH = 1, int KQN = 4 * NDH>
 __global__ __launch_bounds__(WAVES * KS * 64, AMX_ATTN_OCC) void attn_kernel(const AttnParams p) {
     static_assert(NDH == 1 || (KS == 1 && !TSTORE), "the wide form has neither the key split nor the line-patch stores");
+    static_assert(KQN >= 1 && KQN <= 4 * NDH && (KQN == 4 * NDH || !TSTORE), "real 16-column steps of the padded row");
+    constexpr int OBN = (KQN + 1) / 2;  // 32-column blocks of O that hold real columns
     constexpr int DHP = 64 * NDH;      // padded head dimension = elements per Q / K / V row
     constexpr int ROWB = DHP * 2;      // bytes per row of one plane
     constexpr int SUB = KT * 128;      // bytes of one [KT x 64] sub-tile of one plane
@@ -141,13 +147,13 @@ __global__ __launch_bounds__(WAVES * KS * 64, AMX_ATTN_OCC) void attn_kernel(con
     const uint32_t plane_b = (uint32_t)(p.qk_plane * 2);
 
     // Q fragments (B operand): lane (query, hh) holds Q[query][16ks + 8hh + j]
-    V8 qf[NT][4 * NDH];
+    V8 qf[NT][KQN];
     {
         const int qr = query < q_rows ? query : q_rows - 1;
 #pragma unroll
         for (int pl = 0; pl < NT; ++pl)
 #pragma unroll
-            for (int ks = 0; ks < 4 * NDH; ++ks)
+            for (int ks = 0; ks < KQN; ++ks)
                 qf[pl][ks] = *(const V8*)(Qb + (int64_t)pl * p.qk_plane + (int64_t)qr * DHP + ks * 16 + 8 * hh);
     }
 
@@ -185,9 +191,9 @@ __global__ __launch_bounds__(WAVES * KS * 64, AMX_ATTN_OCC) void attn_kernel(con
             vaddr[dt] = TILE + (4 * hh + q4) * 128 + 64 * (dt ^ ((q4 >> 1) & 1)) + 32 * ((lane >> 4) & 1) + 8 * pp;
     }
 
-    f32x16 O[2 * NDH];
+    f32x16 O[OBN];
 #pragma unroll
-    for (int b = 0; b < 2 * NDH; ++b)
+    for (int b = 0; b < OBN; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) O[b][r] = 0.f;
     float m_run = 0.f, l_run = 0.f;  // scores are kept relative to m_run; the first tile sets it
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(WAVES * KS * 64, AMX_ATTN_OCC) void attn_kernel(con
 #pragma unroll
     for (int pl = 0; pl < NT; ++pl)
 #pragma unroll
-        for (int ks = 0; ks < 4 * NDH; ++ks) asm volatile("" ::"v"(qf[pl][ks]));
+        for (int ks = 0; ks < KQN; ++ks) asm volatile("" ::"v"(qf[pl][ks]));
 
 #ifdef AMX_ATTN_STAMP
     // developer diagnostic (tools/attn_bench.hip): cycles per phase of a key tile, summed in scalar registers
@@ -239,7 +245,7 @@ __global__ __launch_bounds__(WAVES * KS * 64, AMX_ATTN_OCC) void attn_kernel(con
 #pragma unroll
             for (int r = 0; r < 16; ++r) X[c][r] = neg_m;
 #pragma unroll
-            for (int kq = 0; kq < 4 * NDH; ++kq) {
+            for (int kq = 0; kq < KQN; ++kq) {
                 const int ks = kq & 3, dsub = (kq >> 2) * SUB;  // K step inside its [KT x 64] sub-tile
 #ifdef AMX_ATTN_ABL_NOLDS  // developer ablation (wrong results): one K fragment read per tile instead of 16
                 const V8 kf = *(const V8*)(sb + kaddr0);
@@ -297,7 +303,7 @@ __global__ __launch_bounds__(WAVES * KS * 64, AMX_ATTN_OCC) void attn_kernel(con
             m_run += d;
             l_run *= alpha;
 #pragma unroll
-            for (int b = 0; b < 2 * NDH; ++b)
+            for (int b = 0; b < OBN; ++b)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) O[b][r] *= alpha;
 #pragma unroll
@@ -348,7 +354,7 @@ __global__ __launch_bounds__(WAVES * KS * 64, AMX_ATTN_OCC) void attn_kernel(con
                 const int koff = c * 4096 + s2 * 2048;  // key rows 32c + 16s2 (+ 8g)
 #endif
 #pragma unroll
-                for (int ob = 0; ob < 2 * NDH; ++ob) {
+                for (int ob = 0; ob < OBN; ++ob) {
                     const int dt = ob & 1, vsub = (ob >> 1) * SUB + koff;  // 32-column block `dt` of V sub-tile ob / 2
                     union { s16x4 h[2]; V8 v; } vf, vl;
                     vf.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(sb + vsub + vaddr[dt]));
@@ -420,7 +426,7 @@ __global__ __launch_bounds__(WAVES * KS * 64, AMX_ATTN_OCC) void attn_kernel(con
             const bool o_il = plane_is_il<NT>(p.out_plane);
             const int64_t col0 = ((packed ? (int64_t)roff : (int64_t)n * p.T) + query) * ((int64_t)p.H * p.dh) + (int64_t)h * p.dh;
 #pragma unroll
-            for (int ob = 0; ob < 2 * NDH; ++ob)
+            for (int ob = 0; ob < OBN; ++ob)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int d0 = ob * 32 + 8 * g + 4 * hh;
@@ -928,24 +934,33 @@ void launch_attn(const AttnParams& p, hipStream_t stream) {
 }  // namespace
 
 // head dimensions other than 64 (AttnParams.dh; rows padded to dhp = 64 or 128): 8-wave workgroups, masked direct stores
-template <typename T, int NT, bool PACKED, int NDH>
+template <typename T, int NT, bool PACKED, int NDH, int KQN = 4 * NDH>
 void launch_attn_other_dh(const AttnParams& p, hipStream_t stream) {
     constexpr int WAVES = 8, KT = 64;
     constexpr int lds = 2 * NT * 2 * KT * 128 * NDH;
     static OncePerDevice attr;
     if (attr.first())
-        (void)hipFuncSetAttribute((const void*)attn_kernel<T, NT, WAVES, KT, PACKED, 1, false, NDH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)attn_kernel<T, NT, WAVES, KT, PACKED, 1, false, NDH, KQN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const int qblocks = (p.T + WAVES * 32 - 1) / (WAVES * 32);
     dim3 grid((unsigned)(8 * ((p.N * p.H + 7) / 8) * qblocks));
-    hipLaunchKernelGGL((attn_kernel<T, NT, WAVES, KT, PACKED, 1, false, NDH>), grid, dim3(WAVES * 64), lds, stream, p);
+    hipLaunchKernelGGL((attn_kernel<T, NT, WAVES, KT, PACKED, 1, false, NDH, KQN>), grid, dim3(WAVES * 64), lds, stream, p);
+}
+
+// 128-wide rows: the instance whose score chain / output blocks stop at the real columns (80: XLS-R 1B; 96; otherwise all 128)
+template <typename T, int NT, bool PACKED>
+void launch_attn_wide(const AttnParams& p, hipStream_t stream) {
+    static const bool whole = dev_switch("AMX_ATTN_WHOLE_ROW");  // developer A/B switch: every padded column, as until round 6
+    if (!whole && p.dh <= 80) launch_attn_other_dh<T, NT, PACKED, 2, 5>(p, stream);
+    else if (!whole && p.dh <= 96) launch_attn_other_dh<T, NT, PACKED, 2, 6>(p, stream);
+    else launch_attn_other_dh<T, NT, PACKED, 2>(p, stream);
 }
 
 template <typename T, int NT>
 void launch_attn_any(const AttnParams& p, hipStream_t stream) {
     if (p.dh != DH) {
         if (p.dhp > 64) {
-            if (p.row_off) launch_attn_other_dh<T, NT, true, 2>(p, stream);
-            else launch_attn_other_dh<T, NT, false, 2>(p, stream);
+            if (p.row_off) launch_attn_wide<T, NT, true>(p, stream);
+            else launch_attn_wide<T, NT, false>(p, stream);
         } else {
             if (p.row_off) launch_attn_other_dh<T, NT, true, 1>(p, stream);
             else launch_attn_other_dh<T, NT, false, 1>(p, stream);

@@ -4,7 +4,7 @@
     AMX_LIB_PATH=$PWD/build/ab/head.so python tools/ab_bitwise.py f16x3 32:10 8:60 > a.txt
     AMX_LIB_PATH=$PWD/build/liballophant_amx_dev.so python tools/ab_bitwise.py f16x3 32:10 8:60 > b.txt; diff a.txt b.txt
 
-Ragged variants (packed rows, the masked last key tile) are hashed as well."""
+Ragged variants (packed rows, the masked last key tile) are hashed as well.  AB_ENCODER selects the encoder (bench.py --encoder)."""
 import hashlib
 import os
 import sys
@@ -19,7 +19,7 @@ from allophant_amd.estimator import Batch, Estimator
 args = sys.argv[1:]
 prec = args[0] if args else "f16x3"
 geometries = [tuple(a.split(":")) for a in args[1:]] or [("4", "10"), ("32", "10"), ("8", "60")]
-spec = bench.build_spec()
+spec = bench.build_spec(encoder_name=os.environ.get("AB_ENCODER", "xlsr"))
 est = Estimator(spec, synthetic.make_state_dict(spec, seed=0), torch.device("cuda", 0), prec)
 tfi = synthetic.make_inventory(spec, 27, seed=0)
 for n, seconds in geometries:
