@@ -2043,8 +2043,10 @@ static int enqueue_pass(amx_handle h, const PassPlan& P, hipStream_t s) {
         Timed t_(h, AMX_KC_ROWNORM);
         launch_ln_finalize((const float2*)ln_partial, D / 64, Mrows, c.eps, (float4*)ln_rowps, (float2*)ln_coef, s);
     };
+    // developer timing switch (WRONG results: every layer runs on layer 0's weights): what weights that are already on the chip are worth
+    static const bool share_weights = dev_switch("AMX_DEV_SHARE_LAYER_WEIGHTS");
     for (int l = 0; l < c.layers; ++l) {
-        const Layer& ly = h->layers[l];
+        const Layer& ly = h->layers[share_weights ? 0 : l];
         if (fold) {
             // the first norm of the stack from the stream itself; later ones: the previous FFN2 left planes and statistics
             if (l == 0) {
