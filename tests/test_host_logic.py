@@ -288,3 +288,14 @@ def test_bench_work_model_matches_the_survey_accounting():
     assert base["gemm_ln_launches"] == 0 and base["gemm_pp_launches"] == 5 + 1 + 4 * 12 + 1
     large = bench.work_model(bench.build_spec(False, "w2v2-large"), 32, 160000, 2)
     assert large["gemm_ln_launches"] == 0 and abs(large["total"] - w["total"]) < 1e9
+    # the XLS-R 1B / 2B shapes (round 6): 48 layers of four ping-pong products + feature projection + phoneme head, the conv stage of
+    # the 300M model; totals from the formulas above at hidden 1280 / 1920
+    from allophant_amd import spec as S
+
+    for name, total, attention in (("xlsr-1b", 34.139, 1.958), ("xlsr-2b", 73.341, 2.937)):
+        spec = bench.build_spec(False, name)
+        S.validate(spec)
+        big = bench.work_model(spec, 32, 160000, 2)
+        assert (big["gemm_pp_launches"], big["gemm_ln_launches"]) == (4 * 48 + 2, 5)
+        assert abs(big["total"] / 1e12 - total) < 0.01 and abs(big["attention"] / 1e12 - attention) < 0.001, (name, big["total"], big["attention"])
+        assert big["gemm_ln"] == w["gemm_ln"] and big["conv0"] == w["conv0"]
