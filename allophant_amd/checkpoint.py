@@ -182,6 +182,15 @@ def check_encoder_against_state(encoder: Dict[str, Any], state: Dict[str, torch.
         f = tuple(state[f"{_ENCODER}layers.0.feed_forward.intermediate_dense.weight"].shape)
         if q[0] != encoder["hidden"] or f[0] != encoder["ffn"]:
             problems.append(f"hidden / ffn described as {encoder['hidden']} / {encoder['ffn']}, the weights are {q[0]} / {f[0]}")
+    # wav2vec 2.0 adapters (`add_adapter`): the reference runs them and reads nothing of their output (spec.validate), so their
+    # weights are simply not uploaded -- unless the adapter changes the width the classifiers were built for, which the reference
+    # itself cannot run (acoustic_model.py:822 sizes them by `output_hidden_size`, the states keep `hidden_size`)
+    adapter = _EXTRACTOR.replace("feature_extractor.conv_layers.", "adapter.")
+    if has(adapter + "proj.weight") and tuple(state[adapter + "proj.weight"].shape)[0] != encoder["hidden"]:
+        problems.append(f"the adapter projects to {tuple(state[adapter + 'proj.weight'].shape)[0]} columns: classifiers sized for that "
+                        f"width cannot read encoder states of {encoder['hidden']} (the reference fails on this checkpoint too)")
+    elif has(adapter + "layers.0.conv.weight"):
+        encoder.setdefault("add_adapter", True)
     if problems:
         raise ValueError(f"the encoder description from {source} does not match the checkpoint's weights: " + "; ".join(problems)
                          + ".  Pass the right description in additional['amx_encoder'].")

@@ -324,6 +324,16 @@ def validate(spec: Dict[str, Any]) -> None:
         raise ValueError("hidden must be a multiple of 8 and at most 2048 (amx_create)")
     if spec["hidden"] % spec["pos_groups"] or (spec["hidden"] // spec["pos_groups"]) % 8 or spec["hidden"] // spec["pos_groups"] > 128:
         raise ValueError("hidden / pos_groups must be a multiple of 8 and at most 128 (amx_create)")
+    if spec.get("add_adapter"):
+        # `Wav2Vec2Config.add_adapter`: the reference reads `.hidden_states` of the HF model (acoustic_model.py:839-847), the tuple of
+        # ENCODER outputs -- the adapter's result only reaches `last_hidden_state`, which nothing reads, and `downsampled_lengths`
+        # (acoustic_model.py:832-835) counts the conv extractor alone.  So an adapter changes no output as long as the classifiers
+        # are built for the encoder's own width; with another `output_hidden_size` the reference sizes them for the adapter's width
+        # (acoustic_model.py:822: `config.output_hidden_size or d_model`) and fails in its first classifier on hidden-size states
+        out_size = spec.get("output_hidden_size")
+        if out_size not in (None, spec["hidden"]):
+            raise ValueError(f"add_adapter with output_hidden_size={out_size} != hidden={spec['hidden']}: the reference sizes its classifiers "
+                             "for the adapter's width but feeds them encoder states (mat1 and mat2 shapes cannot be multiplied)")
     if spec.get("feat_extract_norm", "layer") not in ("layer", "group"):
         # transformers' own message (Wav2Vec2FeatureEncoder.__init__)
         raise ValueError(f"`config.feat_extract_norm` is {spec['feat_extract_norm']}, but has to be one of ['group', 'layer']")

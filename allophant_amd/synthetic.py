@@ -93,6 +93,14 @@ def make_state_dict(spec: Dict[str, Any], seed: int = 0, include_unused: bool = 
         put(p + "final_layer_norm.weight", (D,), 0.1, 1.0)
         put(p + "final_layer_norm.bias", (D,), 0.1)
 
+    if spec.get("add_adapter") and include_unused:
+        # Wav2Vec2Adapter (strided Conv1d + GLU layers behind the encoder): owned by the reference's state dict, computed by its HF
+        # model and never read by `Estimator.predict` (spec.validate) -- the device never receives these tensors
+        k = int(spec.get("adapter_kernel_size", 3))
+        for i in range(int(spec.get("num_adapter_layers", 3))):
+            put(f"{AM}adapter.layers.{i}.conv.weight", (2 * D, D, k), 1.0 / math.sqrt(D * k))
+            put(f"{AM}adapter.layers.{i}.conv.bias", (2 * D,), 0.05)
+
     E = spec.get("embedding_size")
     for node in spec["classes"]:
         p = f"{PROJ}{node['name']}."

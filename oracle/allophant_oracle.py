@@ -149,6 +149,10 @@ def wav2vec2_hidden_states(
 ) -> Tuple[List[Tensor], Tensor, Dict[str, Tensor]]:
     """Returns (hidden_states list of [N,T,D] incl. final LN state, frame lengths, intermediates).
 
+    `add_adapter` (Wav2Vec2Adapter behind the encoder): transformers returns ``hidden_states=encoder_outputs.hidden_states`` -- the
+    adapter's result is `last_hidden_state` only -- and the reference reads the tuple (acoustic_model.py:839-853), so there is
+    nothing to restate: golden g15 (a live adapter in the real reference) equals this function's output.
+
     ``padded`` (no upstream counterpart; the product's AMX_FLAG_PADDED): the batch is a block of a larger batch and keeps
     that batch's padded length, ``audio.shape[1] >= max(lengths)`` -- the mask is built for that length, which is what the
     reference computes for these utterances inside the larger batch."""

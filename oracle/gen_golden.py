@@ -86,6 +86,12 @@ def run_case(name, spec, n, length, ragged, inventory_phones, seed, store_weight
         hf = model._acoustic_model._model(O.zero_mean_unit_var_norm(audio, lengths, mask),
                                           mask.long() if spec.get("use_attention_mask", True) else None,
                                           output_hidden_states=True)
+    if spec.get("add_adapter"):
+        # the adapter is live inside the reference's HF model (its result, strided down, is `last_hidden_state`) -- and `predict` never
+        # sees it: the hidden-state tuple keeps the encoder's frame count, which is also what `pred.lengths` counts
+        assert model._acoustic_model._model.adapter is not None
+        assert hf.last_hidden_state.shape[1] < hf.hidden_states[-1].shape[1] == int(flen.max()), (hf.last_hidden_state.shape, flen)
+        assert all(v.shape[0] == int(flen.max()) for v in pred.outputs.values())
     fm = (torch.arange(flen.max()).unsqueeze(0) < flen.unsqueeze(1)).unsqueeze(-1)
     herr = max(((a - b).abs() * fm).max().item() for a, b in zip(hf.hidden_states, inter["hidden_states"]))
     cerr = ((hf.extract_features - torch.nn.functional.layer_norm(
@@ -221,7 +227,7 @@ def integer_goldens():
 
 def main():
     torch.set_num_threads(8)
-    which = set(sys.argv[1:]) or {"g1", "g2", "g2b", "g3", "g4", "g5", "g8", "g11", "g11b", "g12", "g13", "g13b", "g14"}
+    which = set(sys.argv[1:]) or {"g1", "g2", "g2b", "g3", "g4", "g5", "g8", "g11", "g11b", "g12", "g13", "g13b", "g14", "g15"}
     tiny = S.tiny_encoder(2)
     if "g4" in which:
         integer_goldens()
@@ -330,6 +336,16 @@ def main():
         spec["shared_phones"] = 14
         run_case("g14_xlsr1b_width", spec, n=2, length=32000, ragged=True, inventory_phones=9, seed=14, store_weights=False,
                  subsample=[0, 1, 2], store_audio=False)
+    if "g15" in which:
+        # G15 (round 6): `add_adapter=True` (Wav2Vec2Adapter: three strided Conv1d + GLU layers behind the encoder; the reference builds
+        # whatever the HF config names, acoustic_model.py:796-799).  The reference computes the adapter and reads nothing of it
+        # (`.hidden_states` = encoder outputs, acoustic_model.py:839-853): same outputs, same frame counts as without -- the golden
+        # pins that the drop-in may ignore the adapter's weights
+        enc = S.tiny_encoder(2)
+        enc.update(add_adapter=True, num_adapter_layers=3, adapter_kernel_size=3, adapter_stride=2)
+        spec = S.multitask_spec(enc, ["syllabic", "long"], embedding_size=16, train_phonemes=9, n_features=5, allophone_layer=True)
+        spec["shared_phones"] = 11
+        run_case("g15_tiny_adapter", spec, n=3, length=6400, ragged=True, inventory_phones=7, seed=15, store_weights=False)
     if "g3" in which:
         # G3: full XLS-R shape, procedural weights (seed 0), 2 x 3 s ragged; sub-sampled tensors only
         spec = S.multitask_spec(S.xlsr_300m_encoder(), allophone_layer=True)

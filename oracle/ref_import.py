@@ -188,6 +188,10 @@ def write_hf_model_dir(spec: Dict[str, Any], directory: str) -> str:
         "layerdrop": 0.1, "final_dropout": 0.0,
         "vocab_size": 32,
     }
+    if spec.get("add_adapter"):
+        config.update(add_adapter=True, num_adapter_layers=int(spec.get("num_adapter_layers", 3)),
+                      adapter_kernel_size=int(spec.get("adapter_kernel_size", 3)), adapter_stride=int(spec.get("adapter_stride", 2)),
+                      output_hidden_size=spec.get("output_hidden_size") or spec["hidden"])
     preprocessor = {
         "do_normalize": True, "feature_extractor_type": "Wav2Vec2FeatureExtractor", "feature_size": 1,
         "padding_side": "right", "padding_value": 0, "return_attention_mask": bool(spec.get("use_attention_mask", True)),

@@ -24,7 +24,8 @@ from golden_util import GOLDEN_DIR, Golden, max_abs_valid_bm, max_abs_valid_tm
 pytestmark = pytest.mark.gpu
 
 TINY = ["g1_tiny_multitask", "g2_tiny_hierarchical", "g2b_tiny_hierarchical_blanks", "g5_tiny_baseline",
-        "g8_tiny_time_layer"]  # g8: time-layer (ProjectingMultiheadAttention) classifiers, with and without positions
+        "g8_tiny_time_layer",  # g8: time-layer (ProjectingMultiheadAttention) classifiers, with and without positions
+        "g15_tiny_adapter"]    # g15: add_adapter=True -- the reference runs a Wav2Vec2Adapter and reads nothing of it; its weights stay on the host
 GATE = 1e-3
 LOOSE = {"f16": 6e-2, "bf16": 5e-1}
 

@@ -20,7 +20,10 @@ TINY = ["g1_tiny_multitask", "g2_tiny_hierarchical", "g2b_tiny_hierarchical_blan
         # (attention_mask=None), g11b with the attention mask and a conv bias
         "g11_tiny_groupnorm_postln", "g11b_tiny_groupnorm_masked",
         # head dimensions other than 64 (round 6): 80 (XLS-R 1B's) and 32
-        "g13_tiny_head_dim_80", "g13b_tiny_head_dim_32"]
+        "g13_tiny_head_dim_80", "g13b_tiny_head_dim_32",
+        # `add_adapter=True` (round 6): the reference owns and runs a Wav2Vec2Adapter and reads nothing of it -- the state dict holds
+        # its weights, the outputs and frame counts are those of the encoder alone
+        "g15_tiny_adapter"]
 
 
 @pytest.mark.parametrize("name", TINY)
