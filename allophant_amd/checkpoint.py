@@ -41,6 +41,8 @@ MODEL_ID_ENCODERS = {
     "facebook/wav2vec2-xls-r-2b": _spec.xlsr_2b_encoder,               # hidden 1920 / head_dim 120
     "facebook/wav2vec2-large-xlsr-53": _spec.xlsr_300m_encoder,        # same shape and variant (layer norm, pre-LN, mask)
     "facebook/wav2vec2-large-lv60": _spec.xlsr_300m_encoder,
+    "facebook/mms-300m": _spec.xlsr_300m_encoder,                      # the MMS pre-trained models keep the XLS-R architectures
+    "facebook/mms-1b": _spec.xlsr_1b_encoder,                          # (their fine-tuned ASR heads add `adapter_attn_dim`: refused)
     "facebook/wav2vec2-base": _spec.wav2vec2_base_encoder,             # group norm, post-LN, return_attention_mask=False
     "facebook/wav2vec2-large": _large_groupnorm_encoder,
 }

@@ -281,6 +281,12 @@ def test_checkpoint_model_id_selects_the_wav2vec2_variant():
     assert (restored["hidden"], restored["layers"], restored["heads"], restored["ffn"]) == (768, 12, 12, 3072)
     xlsr = checkpoint.spec_from_checkpoint(checkpoint.make_checkpoint(S.baseline_spec(S.xlsr_300m_encoder(), 40), {}))
     assert xlsr.get("feat_extract_norm", "layer") == "layer" and xlsr.get("stable_layer_norm", True)
+    for model_id, shape in (("facebook/wav2vec2-xls-r-1b", (1280, 48, 16, 5120)), ("facebook/wav2vec2-xls-r-2b", (1920, 48, 16, 7680)),
+                            ("facebook/mms-300m", (1024, 24, 16, 4096)), ("facebook/mms-1b", (1280, 48, 16, 5120))):
+        named = S.baseline_spec(S.xlsr_300m_encoder(), 40)
+        named["model_id"] = model_id
+        wide = checkpoint.spec_from_checkpoint(checkpoint.make_checkpoint(named, {}))
+        assert (wide["hidden"], wide["layers"], wide["heads"], wide["ffn"]) == shape, model_id
     unknown = S.baseline_spec(S.xlsr_300m_encoder(), 40)
     unknown["model_id"] = "someone/some-model"
     with pytest.raises(ValueError):
