@@ -96,9 +96,9 @@ def _raise_reported(statuses: List[int], own: Optional[BaseException]) -> None:
     if own is not None:
         raise own
     if bad:
-        raise RankError(f"rank(s) {bad} reported activations beyond the range of the 16-bit planes in an earlier pass of their "
-                        "shard (AMX_ERANGE): the gathered predictions of that pass are not to be trusted; precision='bf16x3' "
-                        "has the range of fp32")
+        raise RankError(f"rank(s) {bad} reported an error with their shard and raise it themselves: activations beyond the range "
+                        "of the 16-bit planes in an earlier pass (AMX_ERANGE; precision='bf16x3' has the range of fp32), or a shard "
+                        "with more frames than the stated frame count.  The gathered predictions of that pass are not to be trusted")
 
 
 def gather_predictions(local: Optional[Predictions], names_and_classes: List[Tuple[str, int]], total_utterances: int,
@@ -121,9 +121,11 @@ def gather_predictions(local: Optional[Predictions], names_and_classes: List[Tup
     # agree on the padded frame count (ranks may have different local max lengths)
     t_local = 0 if local is None else next(iter(local.outputs.values())).shape[0]
     if frames is not None:
-        if t_local > frames:
-            raise ValueError(f"a shard has {t_local} frames, more than the stated {frames} of the global batch")
         t_max = int(frames)
+        if t_local > t_max and error is None:
+            # a caller's mistake -- but raised HERE, on one rank, in front of the collectives, it would strand the others: the
+            # shard joins them cropped, with its status set, and raises behind them like a range report
+            error = ValueError(f"a shard has {t_local} frames, more than the stated {frames} of the global batch")
     else:
         t_tensor = torch.tensor([t_local], dtype=torch.int64, device=device)
         dist.all_reduce(t_tensor, op=dist.ReduceOp.MAX, group=group)
@@ -138,7 +140,7 @@ def gather_predictions(local: Optional[Predictions], names_and_classes: List[Tup
         col = 0
         for (name, c) in names_and_classes:
             out = local.outputs[name]
-            packed[: out.shape[0], :n_local, col: col + c] = out
+            packed[: min(out.shape[0], t_max), :n_local, col: col + c] = out[:t_max]
             col += c
         lengths[:n_local] = local.lengths.to(device)
     gathered_p = [torch.empty_like(packed) for _ in range(world)] if rank == dst else None

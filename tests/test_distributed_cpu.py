@@ -524,6 +524,20 @@ def _range_report_worker(rank, world, port, result_path):
         log.append("RankError " + str(exc)[:20])
     except FloatingPointError:
         log.append("FloatingPointError")
+    # (c) a shard with more frames than the caller stated for the global batch (rank 1's utterances are the long ones): the same
+    # route -- cropped into the collectives with its status set, ValueError behind them, RankError on the destination
+    from allophant_amd.parallel import gather_predictions
+
+    ragged_lengths = torch.tensor([1200, 1200, 2400, 2400])
+    ragged = Batch(audio * (torch.arange(2400).unsqueeze(0) < ragged_lengths.unsqueeze(1)), ragged_lengths, torch.zeros(4, dtype=torch.long))
+    local = predict(shard_batch(ragged, rank, world, spec=spec))
+    try:
+        gather_predictions(local, names, 4, torch.device("cpu"), dst=0, aliases={"phone": "phoneme"}, frames=S.frame_lengths([1200], spec)[0])
+        log.append("third returned")
+    except RankError:
+        log.append("RankError")
+    except ValueError as exc:
+        log.append("ValueError " + str(exc)[:13])
     # (b) the flat, overlapped gather of DataParallelRunner (bench.py --gpus N): the status travels behind the frame lengths
     calls["n"] = 0
     runner = DataParallelRunner(predict, torch.device("cpu"), dst=0, verify_shapes=False)
@@ -559,6 +573,7 @@ def test_a_range_report_on_one_rank_does_not_hang_the_gather(tmp_path):
     assert r0["log"][0] == "first ok" and r1["log"][0] == "first ok"
     assert r0["log"][1].startswith("RankError")       # the destination learns which rank reported
     assert r1["log"][1] == "FloatingPointError"       # the reporting rank raises its own error -- after the gather
+    assert r0["log"][2] == "RankError" and r1["log"][2] == "ValueError a shard has 7", (r0["log"], r1["log"])
     # flat gather: step 1 of rank 1 reported; rank 0 sees status [0, 1] for that step and 0 otherwise; rank 1 raised once
     assert r1["statuses"].count("raised") == 1
     seen = [s for s in r0["statuses"] if s != "raised"]
