@@ -471,6 +471,16 @@ def test_random_models_and_geometries_against_oracle(amd, seed):
         vrng = np.random.default_rng(5000 + seed)
         spec.update(feat_extract_norm="group" if vrng.integers(0, 2) else "layer", conv_bias=bool(vrng.integers(0, 2)),
                     stable_layer_norm=bool(vrng.integers(0, 2)), use_attention_mask=bool(vrng.integers(0, 2)))
+    # round 6: every third seed takes another head dimension (8 ... 128, the 80 / 96 / 120 of the wide XLS-R models among them)
+    # and, half of those, an adapter the reference computes and never reads -- again from a generator of their own
+    if seed % 3 == 0:
+        hrng = np.random.default_rng(9000 + seed)
+        shapes = [(128, 1, 4), (128, 4, 4), (128, 8, 4), (128, 16, 4), (160, 2, 4), (192, 2, 4), (240, 2, 5), (96, 4, 4), (256, 2, 4)]
+        hidden, heads, groups = shapes[int(hrng.integers(0, len(shapes)))]
+        spec.update(hidden=hidden, heads=heads, ffn=2 * hidden, pos_groups=groups)
+        if hrng.integers(0, 2):
+            spec.update(add_adapter=True, num_adapter_layers=int(hrng.integers(1, 4)))
+        S.validate(spec)
     state = synthetic.make_state_dict(spec, seed=seed)
     composed = bool(spec.get("embedding_size"))
     est = amd.Estimator(spec, state, "cuda:0", "f16x3")
