@@ -139,6 +139,33 @@ def test_xlsr_shape_weight_families_against_oracle(amd, kind):
     est.close()
 
 
+@pytest.mark.parametrize("kind", ["scales", "student_t", "ln_gain", "outlier"])
+def test_layer_norm_fold_under_weight_families(amd, kind):
+    """The weight families above on a batch large enough for the LayerNorm fold (16 x 10 s at XLS-R shape: ``amx_pass_info`` says
+    so) -- the 3 s batches of the test before run the unfused layer.  The fold writes the residual stream as planes of
+    ``(v - pivot) * scale`` with pivot and scale taken from the row statistics of the layer BEFORE: rescaled projections, heavy
+    tails, LayerNorm gains of 8 folded into the FFN weights and a 1e3 outlier channel are what could break that estimate.
+    Utterances 0 and 9 against the CPU oracle on each of them alone (a result does not depend on its batch)."""
+    from oracle import allophant_oracle as O
+
+    spec = S.multitask_spec(S.xlsr_300m_encoder(), allophone_layer=True)
+    spec["shared_phones"] = 80
+    state = _variant(spec, 0, kind)
+    tfi = synthetic.make_inventory(spec, 27, seed=3)
+    audio, lengths = synthetic.make_audio(16, 160000, seed=778)
+    est = amd.Estimator(spec, state, "cuda:0", "f16x3")
+    pred = est.predict(amd.Batch(audio.cuda(), lengths, torch.zeros(16, dtype=torch.long)), tfi)
+    assert est.pass_info()["ln_fold"] == 1
+    est.check_finite()
+    offsets = synthetic.category_offsets(spec)
+    for i in (0, 9):
+        ref, ref_len = O.predict(audio[i:i + 1].contiguous(), lengths[i:i + 1], state, spec, tfi, offsets)
+        t_i = int(ref_len[0])
+        worst = max((pred.outputs[k][:t_i, i].cpu() - ref[k][:t_i, 0]).abs().max().item() for k in ref)
+        assert worst < GATE, (kind, i, worst)
+    est.close()
+
+
 def test_activation_overflow_is_refused_not_silent(amd):
     """FFN1 weights x 2^16: the GELU outputs pass 65504 and cannot be stored as fp16 planes.  The fp16 modes must say so
     (``check_finite`` -> FloatingPointError naming the remedy); bf16x3 planes have the range of fp32 and meet the oracle."""
