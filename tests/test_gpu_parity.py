@@ -384,6 +384,9 @@ def test_full_size_properties(amd):
     tfi = synthetic.make_inventory(spec, 27, seed=0)
     audio, lengths = synthetic.make_audio(32, 160000, seed=1234, ragged=True)
     pred = est.predict(amd.Batch(audio.cuda(), lengths, torch.zeros(32, dtype=torch.long)), tfi)
+    # (round 6) the ragged batch runs on packed rows AND without LayerNorm passes: the fold's row statistics are per packed row
+    info = est.pass_info()
+    assert info["packed"] >= 1 and info["ln_fold"] == 1 and info["rows"] < 32 * 499, info
     assert pred.lengths.tolist() == S.frame_lengths(lengths.tolist(), spec)
     T = pred.outputs["phoneme"].shape[0]
     assert T == 499 and pred.outputs["phoneme"].shape == (499, 32, 28) and len(pred.outputs) == 38
