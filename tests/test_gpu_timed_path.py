@@ -348,3 +348,36 @@ def test_layer_norm_fold_in_every_mode(amd, precision, tolerance):
         assert torch.equal(pred2.outputs[k][:, 0], pred.outputs[k][:, 0]), k    # an utterance's result does not depend on its batch
         assert torch.equal(pred2.outputs[k][:, 17], pred.outputs[k][:, 17]), k
     est.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AMX_LARGE_GEOMETRY_SEEDS", "3"))))
+def test_random_large_geometries_against_oracle(amd, seed):
+    """Round 6: the large-batch forms -- ping-pong GEMMs with the LayerNorm fold, 128- or 256-row producers, packed rows or the padded
+    layout, the long-key attention kernel from 960 frames on -- are chosen by the geometry, and the fixed configurations above pin
+    four of them.  Here the geometry is drawn: 10-40 utterances of 3-24 s (at most 400 s of audio), equal lengths or ragged, at
+    XLS-R shape with the benchmark's weights; two utterances of each batch against the CPU oracle on each of them alone, log-probs
+    within 1e-3 and greedy alignments equal (near-tie escape as above).  ``AMX_LARGE_GEOMETRY_SEEDS`` widens the sweep
+    (``profiles/r06_large_geometry_sweep.log``: 24 seeds)."""
+    import numpy as np
+
+    rng = np.random.default_rng(7000 + seed)
+    spec, _, _, phones, _ = _config(2)
+    state = synthetic.make_state_dict(spec, seed=0)
+    tfi = synthetic.make_inventory(spec, phones, seed=0)
+    seconds = float(rng.uniform(3.0, 24.0))
+    n = int(rng.integers(10, 41))
+    n = max(4, min(n, int(400.0 / seconds)))
+    ragged = bool(rng.integers(0, 2))
+    samples = int(seconds * 16000)
+    audio, lengths = synthetic.make_audio(n, samples, seed=4000 + seed, ragged=ragged)
+    est = amd.Estimator(spec, state, "cuda:0", "f16x3")
+    pred = est.predict(amd.Batch(audio.cuda(), lengths, torch.zeros(n, dtype=torch.long)), tfi, True)
+    info = est.pass_info()
+    est.check_finite()
+    picks = sorted({int(rng.integers(0, n)), int(torch.argmin(lengths)) if ragged else int(rng.integers(0, n))})
+    label = f"random large geometry {seed}: {n} x {seconds:.1f} s {'ragged' if ragged else 'equal'}, fold {info['ln_fold']}, packed {info['packed']}, rows {info['rows']}"
+    print(label)
+    # (the oracle cache is keyed on (config, utterance, length): a key of its own per seed)
+    worst = _check(1000 + seed, spec, state, tfi, audio, lengths, pred, picks, label=label)
+    print(f"{label}: max |log-prob - oracle| = {worst:.2e} on utterances {picks}")
+    est.close()
