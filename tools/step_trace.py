@@ -4,7 +4,7 @@
     rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $ROOT/tools/step_trace.py f16x3 4 10 20
 
 prints the wall time per step; the per-kernel durations come from the profiler's kernel_stats.csv (divide the call counts by
-steps + 3 warm-up steps).  Optional 5th argument: "base" = the wav2vec2-base (group-norm / post-LN) variant."""
+steps + 3 warm-up steps).  Optional 5th argument: "base" = the wav2vec2-base (group-norm / post-LN) variant, "xlsr-1b" / "xlsr-2b" = the wide XLS-R shapes."""
 import os
 import sys
 import time
@@ -24,6 +24,8 @@ variant = sys.argv[5] if len(sys.argv) > 5 else "xlsr"
 if variant == "base":
     spec = S.multitask_spec(S.wav2vec2_base_encoder(), allophone_layer=True)
     spec["shared_phones"] = 80
+elif variant in ("xlsr-1b", "xlsr-2b"):
+    spec = bench.build_spec(encoder_name=variant)
 else:
     spec = bench.build_spec()
 state = synthetic.make_state_dict(spec, seed=0)
